@@ -1,0 +1,394 @@
+// kernels_exact.h -- gfx950 kernels that reproduce the reference's CPU arithmetic bit for bit.
+//
+//  * exact_scores<>      : one lane = one corpus row; the 8-lane stride-8 FMA order of
+//                          dot_avx2_fma / dot_f32_f16base_avx2 / dot_f32_i8_avx2
+//                          (reference src/simd_dot.cpp:26-49, 102-124, 160-199) restated with
+//                          explicit fmaf chains, queries broadcast from SGPRs.
+//  * scan_exact_kernel   : streaming scan with a wavefront-resident top-k (entry j lives in lane j)
+//                          -- the always-correct path (small batches, any dim, overflow fallback,
+//                          threshold bootstrap of the MFMA filter).
+//  * select_kernel       : per-query bitonic sort of the candidate list in LDS, threshold update
+//                          and compaction / final top-k emission, order (score desc, id asc).
+//  * rescore_kernel      : exact scores for the survivors of the MFMA filter.
+//  * merge_topk_kernel   : k-way merge of per-shard lists (multi-GPU).
+//
+// This translation unit is compiled with -ffp-contract=off: the only fused operations are the
+// explicit __builtin_fmaf calls.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "nvdb_common.h"
+
+namespace nvdbhip {
+
+struct Cand { float score; uint32_t row; };   // 8 bytes, one candidate (query implied by the list)
+
+constexpr int DT_F32 = 1, DT_F16 = 2, DT_I8 = 3;
+constexpr float NEG_INF = -__builtin_huge_valf();
+
+__device__ __forceinline__ bool better(float s1, uint32_t i1, float s2, uint32_t i2) {
+  return (s1 > s2) || (s1 == s2 && i1 < i2);
+}
+__device__ __forceinline__ float half_bits_to_float(uint32_t h16) {
+  return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h16)));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l) {
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), l));
+}
+__device__ __forceinline__ float hsum8(const float (&a)[8]) {
+  // (lo+hi), hadd, hadd  (simd_dot.cpp:38-44)
+  const float s0 = a[0] + a[4], s1 = a[1] + a[5], s2 = a[2] + a[6], s3 = a[3] + a[7];
+  return (s0 + s1) + (s2 + s3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact scores of ONE corpus row against QG queries (q is wave-uniform -> scalar loads)
+// ------------------------------------------------------------------------------------------------
+template <int DT, bool ALIGNED>
+__device__ __forceinline__ void load8(const void* __restrict__ rowp, uint32_t i, float (&x)[8]) {
+  if constexpr (DT == DT_F16) {
+    if constexpr (ALIGNED) {
+      const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const char*>(rowp) + 2 * i);
+      x[0] = half_bits_to_float(v.x & 0xFFFFu); x[1] = half_bits_to_float(v.x >> 16);
+      x[2] = half_bits_to_float(v.y & 0xFFFFu); x[3] = half_bits_to_float(v.y >> 16);
+      x[4] = half_bits_to_float(v.z & 0xFFFFu); x[5] = half_bits_to_float(v.z >> 16);
+      x[6] = half_bits_to_float(v.w & 0xFFFFu); x[7] = half_bits_to_float(v.w >> 16);
+    } else {
+      const unsigned short* p = static_cast<const unsigned short*>(rowp) + i;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = half_bits_to_float(p[j]);
+    }
+  } else if constexpr (DT == DT_F32) {
+    if constexpr (ALIGNED) {
+      const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(rowp) + i);
+      const float4 b = *reinterpret_cast<const float4*>(static_cast<const float*>(rowp) + i + 4);
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+      const float* p = static_cast<const float*>(rowp) + i;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = p[j];
+    }
+  } else {
+    if constexpr (ALIGNED) {   // 8-byte aligned groups of 8 int8
+      const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const char*>(rowp) + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = static_cast<float>(static_cast<int>(v.x << (24 - 8 * j)) >> 24);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[4 + j] = static_cast<float>(static_cast<int>(v.y << (24 - 8 * j)) >> 24);
+    } else {
+      const signed char* p = static_cast<const signed char*>(rowp) + i;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = static_cast<float>(p[j]);
+    }
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ float load1(const void* __restrict__ rowp, uint32_t i) {
+  if constexpr (DT == DT_F16) return half_bits_to_float(static_cast<const unsigned short*>(rowp)[i]);
+  else if constexpr (DT == DT_F32) return static_cast<const float*>(rowp)[i];
+  else return static_cast<float>(static_cast<const signed char*>(rowp)[i]);
+}
+
+// out[g] = reference score of (query g, this row).  q points at query 0 of the group, queries are
+// `dim` floats apart.  `scale` is the row's int8 scale (ignored otherwise).
+template <int DT, int QG, bool ALIGNED>
+__device__ __forceinline__ void exact_scores(const void* __restrict__ rowp, const float* __restrict__ q,
+                                             uint32_t dim, float scale, float (&out)[QG]) {
+  float acc[QG][8];
+#pragma unroll
+  for (int g = 0; g < QG; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+
+  // vector body: f32/f16 consume floor(dim/8)*8 elements (simd_dot.cpp:31, 106), int8 consumes
+  // floor(dim/16)*16 (simd_dot.cpp:164) -- two groups of 8 into the same accumulators.
+  const uint32_t body = (DT == DT_I8) ? (dim & ~15u) : (dim & ~7u);
+  uint32_t i = 0;
+#pragma unroll 2
+  for (; i < body; i += 8) {
+    float x[8];
+    load8<DT, ALIGNED>(rowp, i, x);
+#pragma unroll
+    for (int g = 0; g < QG; ++g)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[g][j] = __builtin_fmaf(q[g * dim + i + j], x[j], acc[g][j]);
+  }
+#pragma unroll
+  for (int g = 0; g < QG; ++g) out[g] = hsum8(acc[g]);
+
+  // tails (see oracle/nvdb_oracle.c oracle_dot_f32 for the f32 rule: a group of four unfused
+  // multiply+add, then fused; f16 and int8 tails are fused throughout)
+  if (i < dim) {
+    if constexpr (DT == DT_F32) {
+      if (dim - i >= 4) {
+        for (int j = 0; j < 4; ++j) {
+          const float x = load1<DT>(rowp, i + j);
+#pragma unroll
+          for (int g = 0; g < QG; ++g) { const float p = q[g * dim + i + j] * x; out[g] = out[g] + p; }
+        }
+        i += 4;
+      }
+    }
+    for (; i < dim; ++i) {
+      const float x = load1<DT>(rowp, i);
+#pragma unroll
+      for (int g = 0; g < QG; ++g) out[g] = __builtin_fmaf(q[g * dim + i], x, out[g]);
+    }
+  }
+  if constexpr (DT == DT_I8) {
+#pragma unroll
+    for (int g = 0; g < QG; ++g) out[g] = out[g] * scale;   // simd_dot.cpp:198
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ const void* row_ptr(const void* rows, uint64_t row, uint32_t dim) {
+  constexpr int BPE = (DT == DT_F32) ? 4 : (DT == DT_F16 ? 2 : 1);
+  return static_cast<const char*>(rows) + row * static_cast<uint64_t>(dim) * BPE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wavefront-resident top-k: entry j (best first) lives in lane j; k <= 64
+// ------------------------------------------------------------------------------------------------
+struct WaveTopK {
+  float s;        // per lane
+  uint32_t id;    // per lane
+  uint32_t cnt;   // uniform
+  float thr_s;    // uniform: worst kept entry once cnt == k
+  uint32_t thr_id;
+};
+
+__device__ __forceinline__ void wtk_init(WaveTopK& t) {
+  t.s = NEG_INF; t.id = 0xFFFFFFFFu; t.cnt = 0; t.thr_s = NEG_INF; t.thr_id = 0xFFFFFFFFu;
+}
+__device__ __forceinline__ bool wtk_accepts(const WaveTopK& t, uint32_t k, float s, uint32_t id) {
+  return t.cnt < k || better(s, id, t.thr_s, t.thr_id);
+}
+// all lanes call with the same (s,id)
+__device__ __forceinline__ void wtk_insert(WaveTopK& t, uint32_t k, float s, uint32_t id, int lane) {
+  const bool b = (static_cast<uint32_t>(lane) < t.cnt) && better(t.s, t.id, s, id);
+  const uint32_t pos = static_cast<uint32_t>(__builtin_popcountll(__ballot(b)));
+  if (pos >= k) return;
+  const float up_s = __shfl_up(t.s, 1);
+  const uint32_t up_id = __shfl_up(t.id, 1);
+  if (static_cast<uint32_t>(lane) > pos) { t.s = up_s; t.id = up_id; }
+  else if (static_cast<uint32_t>(lane) == pos) { t.s = s; t.id = id; }
+  if (t.cnt < k) ++t.cnt;
+  if (t.cnt == k) { t.thr_s = readlane_f(t.s, static_cast<int>(k) - 1); t.thr_id = readlane_u(t.id, static_cast<int>(k) - 1); }
+}
+// offer each lane's (s,id) where `pass` is set
+__device__ __forceinline__ void wtk_offer(WaveTopK& t, uint32_t k, bool pass, float s, uint32_t id, int lane) {
+  unsigned long long m = __ballot(pass);
+  while (m) {
+    const int L = __builtin_ctzll(m);
+    m &= m - 1;
+    const float cs = readlane_f(s, L);
+    const uint32_t cid = readlane_u(id, L);
+    if (wtk_accepts(t, k, cs, cid)) wtk_insert(t, k, cs, cid, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact streaming scan.  grid = (row splits P, ceil(nq/QG)); block = 256 (4 waves).
+// Each workgroup scans rows [lo,hi) of the chunk for QG queries and appends its <= k best
+// entries per query (those that also clear the query's global threshold) to the candidate lists.
+// ------------------------------------------------------------------------------------------------
+template <int DT, int QG, bool ALIGNED>
+__global__ __launch_bounds__(256) void scan_exact_kernel(
+    const void* __restrict__ rows, const float* __restrict__ scales, uint32_t dim, uint32_t row_lo, uint32_t row_hi,
+    const float* __restrict__ q32, uint32_t nq, uint32_t q_first, uint32_t k, const float* __restrict__ thr,
+    Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t* __restrict__ overflow) {
+  __shared__ float lds_s[4][QG][64];
+  __shared__ uint32_t lds_id[4][QG][64];
+  __shared__ uint32_t lds_cnt[4][QG];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t P = gridDim.x, p = blockIdx.x;
+  const uint64_t span = static_cast<uint64_t>(row_hi - row_lo);
+  const uint32_t lo = row_lo + static_cast<uint32_t>(span * p / P);
+  const uint32_t hi = row_lo + static_cast<uint32_t>(span * (p + 1) / P);
+  const uint32_t qg0 = q_first + blockIdx.y * QG;           // first query of this group (uniform)
+
+  // queries beyond nq: point at the last valid query and drop the result
+  const uint32_t qbase = (qg0 + QG <= nq) ? qg0 : (nq >= static_cast<uint32_t>(QG) ? nq - QG : 0u);
+  const float* __restrict__ qptr = q32 + static_cast<uint64_t>(qbase) * dim;
+
+  WaveTopK tk[QG];
+  float gthr[QG];
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    wtk_init(tk[g]);
+    const uint32_t qi = qbase + g;
+    gthr[g] = (thr != nullptr && qi < nq) ? thr[qi] : NEG_INF;
+  }
+
+  for (uint32_t base = lo + wave * 64u; base < hi; base += 256u) {
+    const uint32_t row = base + lane;
+    const bool valid = row < hi;
+    const uint32_t rrow = valid ? row : (hi - 1);
+    float sc[QG];
+    const float scale = (DT == DT_I8) ? scales[rrow] : 1.f;
+    exact_scores<DT, QG, ALIGNED>(row_ptr<DT>(rows, rrow, dim), qptr, dim, scale, sc);
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      const bool pass = valid && sc[g] >= gthr[g] && wtk_accepts(tk[g], k, sc[g], row);
+      wtk_offer(tk[g], k, pass, sc[g], row, lane);
+    }
+  }
+
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    lds_s[wave][g][lane] = tk[g].s;
+    lds_id[wave][g][lane] = tk[g].id;
+    if (lane == 0) lds_cnt[wave][g] = tk[g].cnt;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    for (int w = 1; w < 4; ++w) {
+      const uint32_t c = lds_cnt[w][g];
+      for (uint32_t j = 0; j < c; ++j) {
+        const float cs = lds_s[w][g][j];
+        const uint32_t cid = lds_id[w][g][j];
+        if (wtk_accepts(tk[g], k, cs, cid)) wtk_insert(tk[g], k, cs, cid, lane);
+      }
+    }
+    const uint32_t qi = qbase + g;
+    // groups that were shifted back to stay in range own only the queries >= qg0
+    const bool own = qi >= qg0 && qi < nq;
+    if (own && tk[g].cnt > 0) {
+      uint32_t slot0 = 0;
+      if (lane == 0) slot0 = atomicAdd(&cnt[qi], tk[g].cnt);
+      slot0 = readlane_u(slot0, 0);
+      if (static_cast<uint32_t>(lane) < tk[g].cnt) {
+        const uint32_t slot = slot0 + lane;
+        if (slot < cap) cand[static_cast<uint64_t>(qi) * cap + slot] = Cand{tk[g].s, tk[g].id};
+        else overflow[qi] = 1u;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// select: sort a query's candidate list (score desc, id asc) in LDS, then either
+//   mode 0: thr[q] = (k-th score) - slack[q]; keep every entry with score >= thr (all of the top-k
+//           plus whatever lies inside the filter's error band); write the list back compacted;
+//   mode 1: emit the final top-k (global ids, padded with UINT64_MAX / -inf).
+// grid = nq, block = 256, dynamic LDS = cap * 8 bytes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_kernel(
+    Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t k, const float* __restrict__ slack,
+    float* __restrict__ thr, uint32_t* __restrict__ overflow, int mode, uint64_t row_base,
+    unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, uint32_t out_k) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  Cand* e = reinterpret_cast<Cand*>(smem_raw);
+  __shared__ uint32_t s_keep;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  uint32_t m = cnt[q];
+  if (m > cap) { if (tid == 0) overflow[q] = 1u; m = cap; }
+  uint32_t M2 = 1;
+  while (M2 < m) M2 <<= 1;
+  Cand* mine = cand + static_cast<uint64_t>(q) * cap;
+  for (uint32_t i = tid; i < M2; i += 256) e[i] = (i < m) ? mine[i] : Cand{NEG_INF, 0xFFFFFFFFu};
+  __syncthreads();
+  for (uint32_t size = 2; size <= M2; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t i = tid; i < (M2 >> 1); i += 256) {
+        const uint32_t a = 2 * i - (i & (stride - 1));   // index with bit `stride` clear
+        const uint32_t b = a + stride;
+        const bool desc = ((a & size) == 0);             // first half of each 2*size block: best first
+        const Cand ea = e[a], eb = e[b];
+        const bool b_better = better(eb.score, eb.row, ea.score, ea.row);
+        if (b_better == desc) { e[a] = eb; e[b] = ea; }
+      }
+      __syncthreads();
+    }
+  }
+  if (mode == 1) {
+    const uint32_t c = m < k ? m : k;
+    for (uint32_t j = tid; j < out_k; j += 256) {
+      const bool have = j < c;
+      out_ids[static_cast<uint64_t>(q) * out_k + j] = have ? (row_base + e[j].row) : ~0ull;
+      out_scores[static_cast<uint64_t>(q) * out_k + j] = have ? e[j].score : NEG_INF;
+    }
+    return;
+  }
+  const float kth = (m >= k) ? e[k - 1].score : NEG_INF;
+  const float sl = slack ? slack[q] : 0.f;
+  const float t = kth - sl;
+  if (tid == 0) s_keep = 0;
+  __syncthreads();
+  uint32_t local = 0;
+  if (sl > 0.f) { for (uint32_t i = tid; i < m; i += 256) local += (e[i].score >= t) ? 1u : 0u; }
+  else { for (uint32_t i = tid; i < m; i += 256) local += (i < k) ? 1u : 0u; }
+  if (local) atomicAdd(&s_keep, local);
+  __syncthreads();
+  const uint32_t keep = s_keep;                          // sorted list -> the kept ones are a prefix
+  for (uint32_t i = tid; i < keep; i += 256) mine[i] = e[i];
+  if (tid == 0) { cnt[q] = keep; thr[q] = t; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rescore: replace the filter score of every surviving candidate by the exact reference score;
+// count violations of the filter's error bound (must stay 0).  grid = nq, block = 256.
+// ------------------------------------------------------------------------------------------------
+template <int DT, bool ALIGNED>
+__global__ __launch_bounds__(256) void rescore_kernel(
+    const void* __restrict__ rows, const float* __restrict__ scales, uint32_t dim, const float* __restrict__ q32,
+    Cand* __restrict__ cand, const uint32_t* __restrict__ cnt, uint32_t cap, const float* __restrict__ ebound,
+    uint32_t* __restrict__ violations, unsigned long long* __restrict__ total_cands) {
+  const uint32_t q = blockIdx.x;
+  uint32_t m = cnt[q];
+  if (m > cap) m = cap;
+  if (threadIdx.x == 0 && total_cands) atomicAdd(total_cands, static_cast<unsigned long long>(m));
+  const float* __restrict__ qptr = q32 + static_cast<uint64_t>(q) * dim;
+  const float eb = ebound ? ebound[q] : 0.f;
+  Cand* mine = cand + static_cast<uint64_t>(q) * cap;
+  for (uint32_t i = threadIdx.x; i < m; i += 256) {
+    const Cand c = mine[i];
+    float sc[1];
+    const float scale = (DT == DT_I8) ? scales[c.row] : 1.f;
+    exact_scores<DT, 1, ALIGNED>(row_ptr<DT>(rows, c.row, dim), qptr, dim, scale, sc);
+    if (ebound && !(__builtin_fabsf(sc[0] - c.score) <= eb)) atomicAdd(violations, 1u);
+    mine[i].score = sc[0];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of per-shard top-k lists: in[s][nq][k] -> out[nq][k]; rank-based (entries are unique).
+// grid = nq, block = 256; nshards*k <= 4096.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_topk_kernel(
+    const unsigned long long* __restrict__ ids, const float* __restrict__ scores, uint32_t nshards, uint32_t nq,
+    uint32_t k, unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const uint32_t m = nshards * k, q = blockIdx.x;
+  float* s = reinterpret_cast<float*>(smem_raw);
+  unsigned long long* id = reinterpret_cast<unsigned long long*>(smem_raw + ((m * 4 + 15) & ~15u));
+  for (uint32_t i = threadIdx.x; i < m; i += 256) {
+    const uint32_t sh = i / k, j = i % k;
+    s[i] = scores[(static_cast<uint64_t>(sh) * nq + q) * k + j];
+    id[i] = ids[(static_cast<uint64_t>(sh) * nq + q) * k + j];
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < m; i += 256) {
+    const float si = s[i];
+    const unsigned long long ii = id[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < m; ++j) {
+      const float sj = s[j];
+      const unsigned long long ij = id[j];
+      // padding entries (id == ~0) sort last; equal pads are ordered by position
+      const bool jb = (sj > si) || (sj == si && (ij < ii || (ij == ii && j < i)));
+      rank += jb ? 1u : 0u;
+    }
+    if (rank < k) { out_ids[static_cast<uint64_t>(q) * k + rank] = ii; out_scores[static_cast<uint64_t>(q) * k + rank] = si; }
+  }
+}
+
+}  // namespace nvdbhip

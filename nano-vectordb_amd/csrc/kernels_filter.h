@@ -1,0 +1,339 @@
+// kernels_filter.h -- the hot kernel: MFMA filter scan of the fp16 / int8 corpus (gfx950, CDNA4).
+//
+// Dataflow (DESIGN.md "filter kernel"):
+//   * a workgroup = 4 wavefronts = one per SIMD, 512-register budget each; it owns 256 queries
+//     (64 per wave).  Every wave keeps its 64 queries' B-operand fragments for the WHOLE K = DIM
+//     in registers (DIM/2 VGPRs) for the lifetime of the kernel -- queries are the stationary
+//     operand, they never touch LDS and are read from memory exactly once per launch.
+//   * the corpus is the streamed operand: tiles of 32 rows x DIM (48 KB at DIM=768, fp16) go
+//     HBM -> LDS with direct-to-LDS loads (global_load_lds_dwordx4, 1 KB per wave-instruction),
+//     three stages deep, one s_barrier per tile, counted vmcnt so two tiles stay in flight.
+//   * per tile and wave: DIM/16 ds_read_b128 (A fragment, XOR-swizzled image, conflict-free) feed
+//     2*DIM/16 v_mfma_f32_32x32x16_f16 (two 32-query blocks share each A fragment).
+//   * epilogue: accumulator D[row][query] has the query on the lane, so the per-query threshold
+//     is one VGPR; 32 compares per tile; survivors (rare) are appended to the query's candidate
+//     list with a global atomic.  Nothing else is written: the B x N score matrix never exists.
+//
+// The MFMA result is only a FILTER: |filter - reference score| <= ebound[q] (prep kernel), every
+// survivor is re-scored in the reference's exact fp32 order afterwards (kernels_exact.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_exact.h"
+
+namespace nvdbhip {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef int intx16 __attribute__((ext_vector_type(16)));
+typedef int int4_t __attribute__((ext_vector_type(4)));
+
+#define NVDB_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define NVDB_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int FILTER_ROWS = 32;          // corpus rows per tile (MFMA M)
+constexpr int FILTER_QPW = 64;           // queries per wave (2 MFMA N-blocks)
+constexpr int FILTER_QPB = 256;          // queries per workgroup
+constexpr int FILTER_STAGES = 3;
+
+// ------------------------------------------------------------------------------------------------
+// query preparation for the fp16 filter.
+//   q16[q][i]  = half( q[i] * 2^e ),  e chosen so that max|q| * 2^e is in [2^14, 2^15)
+//                (keeps small elements out of the half subnormal range; exact power-of-two scale)
+//   qscale[q]  = 2^e,   qinv[q] = 2^-e
+//   ebound[q]  = REL * ||q|| * max_row_norm  >= |filter - reference score|
+//   slack[q]   = 2 * ebound[q]
+// grid = nq_pad (multiple of 256), block = 256.  Pad queries get zeros.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim,
+                                                       float max_row_norm, float rel, _Float16* __restrict__ q16,
+                                                       float* __restrict__ qscale, float* __restrict__ qinv,
+                                                       float* __restrict__ ebound, float* __restrict__ slack) {
+  __shared__ float red_max[4], red_ss[4];
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  if (q >= nq) {
+    for (uint32_t i = tid; i < dim; i += 256) q16[static_cast<uint64_t>(q) * dim + i] = static_cast<_Float16>(0.f);
+    if (tid == 0) { qscale[q] = 1.f; qinv[q] = 1.f; ebound[q] = 0.f; slack[q] = 0.f; }
+    return;
+  }
+  const float* src = q32 + static_cast<uint64_t>(q) * dim;
+  float mx = 0.f, ss = 0.f;
+  for (uint32_t i = tid; i < dim; i += 256) { const float v = src[i]; mx = fmaxf(mx, fabsf(v)); ss = __builtin_fmaf(v, v, ss); }
+  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); ss += __shfl_xor(ss, o); }
+  if ((tid & 63) == 0) { red_max[tid >> 6] = mx; red_ss[tid >> 6] = ss; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
+  ss = (red_ss[0] + red_ss[1]) + (red_ss[2] + red_ss[3]);
+  int e = 0;
+  if (mx > 0.f && mx < 3.0e38f) {
+    int ex; (void)frexpf(mx, &ex);          // mx = m * 2^ex, m in [0.5,1)  -> mx in [2^(ex-1), 2^ex)
+    e = 15 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  }
+  const float sc = ldexpf(1.f, e);
+  for (uint32_t i = tid; i < dim; i += 256) q16[static_cast<uint64_t>(q) * dim + i] = static_cast<_Float16>(src[i] * sc);
+  if (tid == 0) {
+    const float nrm = sqrtf(ss) * 1.0001f;
+    const float eb = rel * nrm * max_row_norm + 1e-30f;
+    qscale[q] = sc; qinv[q] = ldexpf(1.f, -e); ebound[q] = eb; slack[q] = 2.f * eb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16 MFMA filter scan of rows [row_lo,row_hi), (row_hi-row_lo) % 32 == 0 (the host gives the
+// ragged tail to the exact scan).
+//   grid   = S * QT workgroups (S row streams x QT query tiles of 256), block = 256
+//   LDS    = 3 stages x 32 rows x DIM x 2 bytes (dynamic)
+//   DIM % 128 == 0 (bank-swizzle arithmetic below), rows 16-byte aligned.
+// Workgroup b: XCD label b % 8; the QT workgroups that stream the same rows against different
+// query tiles are consecutive on the same XCD label so that they share that XCD's L2.
+//
+// Register plan (one wave per SIMD, 512 registers): the 64 queries' B fragments take DIM/2
+// registers; the first 64 fragments live in AGPRs, the rest in VGPRs, and the MFMAs are issued
+// from inline asm so that they read the AGPR-resident fragments in place (the compiler's builtin
+// only takes VGPR sources and would copy 4 registers per MFMA).  What the compiler cannot see
+// inside the asm is handled here: the first MFMA of a tile takes the literal 0 as C (no VALU
+// write feeding an MFMA), accumulator chains reuse exactly the same 16 registers, and 32 wait
+// states separate the last MFMA from the first VALU read of the accumulators.
+// ------------------------------------------------------------------------------------------------
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+#define NVDB_MFMA_F16_ZERO_A(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b))
+#define NVDB_MFMA_F16_ZERO_V(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b))
+#define NVDB_MFMA_F16_ACC_A(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
+#define NVDB_MFMA_F16_ACC_V(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+
+// Direct-to-LDS 16-byte load issued from inline asm: LDS address = M0 (wave-uniform byte offset)
+// + lane*16, global address = sbase + voff.  Issued from asm on purpose: hipcc treats a
+// __builtin_amdgcn_global_load_lds as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front
+// of the next ds_read, which would drain the two tiles this kernel keeps in flight.  The kernel
+// counts these loads itself (s_waitcnt vmcnt(PPW) + s_barrier before a stage is read).
+__device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_t lds_off) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_off), "s"(sbase) : "memory");
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256, 1) void filter_f16_kernel(
+    const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
+    uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
+    const float* __restrict__ qinv, Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap,
+    uint32_t* __restrict__ overflow) {
+  constexpr int KSTEPS = DIM / 16;                 // MFMA k-steps per tile
+  constexpr int ROW_BYTES = DIM * 2;
+  constexpr int STAGE_BYTES = FILTER_ROWS * ROW_BYTES;
+  constexpr int PIECES = STAGE_BYTES / 1024;       // 1 KB direct-to-LDS pieces per stage
+  constexpr int PPW = PIECES / 4;                  // pieces per wave
+  constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
+  constexpr int NFRAG = 2 * KSTEPS;                // B fragments per wave (2 query blocks)
+  constexpr int NFRAG_A = NFRAG < 64 ? NFRAG : 64; // ... of which this many live in AGPRs
+  constexpr int NFRAG_V = NFRAG - NFRAG_A;
+  static_assert(DIM % 128 == 0, "swizzle assumes row stride is a multiple of 256 bytes");
+  static_assert(PIECES % 4 == 0, "pieces must split evenly over 4 waves");
+  static_assert(KSTEPS <= 64, "query block 0 must fit the AGPR-resident fragments");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, hsel = lane >> 5;
+
+  // ---- workgroup -> (row stream, query tile) ---------------------------------------------------
+  const uint32_t nwg = gridDim.x, b = blockIdx.x;
+  const uint32_t S = nwg / QT;
+  uint32_t stream, qt;
+  if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) {
+    const uint32_t xcd = b & 7u, i = b >> 3;       // i-th workgroup of this XCD label
+    qt = i % QT;
+    stream = (i / QT) * 8u + xcd;
+  } else { qt = b % QT; stream = b / QT; }
+  const uint32_t tiles_total = (row_hi - row_lo) / FILTER_ROWS;
+  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
+  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const uint32_t NT = t_hi - t_lo;
+  if (NT == 0) return;
+
+  // ---- stationary operand: this wave's 64 queries, all of K, in registers ----------------------
+  // fragment f = nb*KSTEPS + s : query block nb (32 queries), k-step s.  Lane (r31,hsel) holds
+  // q16[query r31 of the block][16 s + 8 hsel .. +8] -- the same k-slice the A fragment holds, so
+  // the MFMA's internal k order is irrelevant.
+  const uint32_t qbase = qt * FILTER_QPB + wave * FILTER_QPW;
+  float4_t bqa[NFRAG_A];
+  float4_t bqv[NFRAG_V > 0 ? NFRAG_V : 1];
+#pragma unroll
+  for (int f = 0; f < NFRAG; ++f) {
+    const int nb = f / KSTEPS, s = f % KSTEPS;
+    const float4_t v = *reinterpret_cast<const float4_t*>(q16 + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 16 * s + 8 * hsel);
+    if (f < NFRAG_A) bqa[f] = v; else bqv[f - NFRAG_A] = v;
+  }
+  // Make the compiler retire these loads HERE (an empty asm that reads every fragment): left to
+  // itself it defers its `s_waitcnt vmcnt(n)` for them to the first use inside the tile loop,
+  // where they would also drain the direct-to-LDS loads this kernel keeps in flight.
+#pragma unroll
+  for (int f = 0; f < NFRAG_A; ++f) asm volatile("" ::"a"(bqa[f]));
+#pragma unroll
+  for (int f = 0; f < NFRAG_V; ++f) asm volatile("" ::"v"(bqv[f]));
+  float thr_s[2], inv_s[2];
+  uint32_t qid[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    qid[nb] = qbase + nb * 32 + r31;
+    const bool real = qid[nb] < nq;
+    thr_s[nb] = real ? thr[qid[nb]] * qscale[qid[nb]] : __builtin_huge_valf();
+    inv_s[nb] = real ? qinv[qid[nb]] : 0.f;
+  }
+
+  asm volatile("" ::"v"(thr_s[0]), "v"(thr_s[1]), "v"(inv_s[0]), "v"(inv_s[1]));
+
+  // ---- per-lane source offsets of this wave's direct-to-LDS pieces -----------------------------
+  // LDS image of a stage: [32 rows][CHUNKS_PER_ROW 16-byte chunks], chunk c of row r stored at
+  // chunk position c ^ (r & 15) (XOR stays inside a 16-chunk = 256-byte bank row).  The LDS side of
+  // a direct-to-LDS load is linear (M0 base + lane*16), so the permutation is applied to the
+  // per-lane GLOBAL address: LDS position P = piece*64 + lane  <-  row P / CPR, chunk (P % CPR) ^ (row & 15).
+  uint32_t src_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const uint32_t P = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
+    const uint32_t r = P / CHUNKS_PER_ROW, cpos = P % CHUNKS_PER_ROW;
+    src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
+  }
+  // A-fragment read offset: lane (r31,hsel) reads chunk 2s+hsel of row r31, stored at position
+  // (2s+hsel) ^ (r31&15); since 2s+hsel == 2s ^ hsel this is a_base ^ ((s&7) << 5) + 256*(s>>3).
+  const uint32_t a_base = r31 * ROW_BYTES + ((static_cast<uint32_t>(hsel) ^ (r31 & 15u)) << 4);
+
+  const char* gbase = reinterpret_cast<const char*>(rows);
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
+  // tile t_rel of this stream (clamped: past-the-end tiles re-load the last one, harmlessly)
+  auto tile_ptr = [&](uint32_t t_rel) -> const char* {
+    const uint32_t t = t_lo + (t_rel < NT ? t_rel : NT - 1);
+    return gbase + static_cast<uint64_t>(row_lo + t * FILTER_ROWS) * ROW_BYTES;
+  };
+  auto issue_piece = [&](const char* tile, uint32_t buf, int i) {
+    glds16(src_off[i], tile, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
+  };
+
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) issue_piece(tile_ptr(0), 0, i);
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) issue_piece(tile_ptr(1), 1, i);
+
+  constexpr int RING = 4;                          // A fragments in flight LDS -> VGPR
+  constexpr int PIECE_EVERY = KSTEPS / PPW;        // one direct-to-LDS piece per this many k-steps
+  static_assert(KSTEPS % PPW == 0 && KSTEPS >= RING, "schedule assumes KSTEPS is a multiple of PPW");
+
+  for (uint32_t t = 0; t < NT; ++t) {
+    // my pieces of tile t have landed once all but the newest stage's PPW loads are complete
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    __builtin_amdgcn_s_barrier();                  // everyone's pieces landed; buffer (t+2)%3 is free
+
+    const char* next_tile = tile_ptr(t + 2);
+    const uint32_t next_buf = (t + 2) % FILTER_STAGES;
+    const char* stage = smem + (t % FILTER_STAGES) * STAGE_BYTES;
+    auto read_a = [&](int s) -> float4_t {
+      return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256);
+    };
+    float4_t ar[RING];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(s);
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      // keep RING-1 fragment reads ahead of the MFMAs; the slot written here was consumed by step s-1
+      if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1);
+      const float4_t a = ar[s % RING];
+      const int f1 = KSTEPS + s;
+      if (s == 0) {
+        NVDB_MFMA_F16_ZERO_A(acc0, a, bqa[0]);
+        if (f1 < NFRAG_A) NVDB_MFMA_F16_ZERO_A(acc1, a, bqa[f1 < NFRAG_A ? f1 : 0]);
+        else NVDB_MFMA_F16_ZERO_V(acc1, a, bqv[f1 >= NFRAG_A ? f1 - NFRAG_A : 0]);
+      } else {
+        NVDB_MFMA_F16_ACC_A(acc0, a, bqa[s]);
+        if (f1 < NFRAG_A) NVDB_MFMA_F16_ACC_A(acc1, a, bqa[f1 < NFRAG_A ? f1 : 0]);
+        else NVDB_MFMA_F16_ACC_V(acc1, a, bqv[f1 >= NFRAG_A ? f1 - NFRAG_A : 0]);
+      }
+      // stream tile t+2 in behind the MFMAs, one 1 KB piece every PIECE_EVERY k-steps
+      if (s % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_tile, next_buf, s / PIECE_EVERY);
+    }
+    // 32 wait states: MFMA result -> VALU read (the compiler does not see inside the asm)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc0), "+v"(acc1));
+
+    // ---- epilogue: threshold filter ------------------------------------------------------------
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) any |= (acc0[r] >= thr_s[0]) | (acc1[r] >= thr_s[1]);
+    if (__builtin_amdgcn_ballot_w64(any)) {
+      const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = nb == 0 ? acc0[r] : acc1[r];
+          const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+          if (v >= thr_s[nb] && row < row_hi) {
+            const uint32_t slot = atomicAdd(&cnt[qid[nb]], 1u);
+            if (slot < cap) cand[static_cast<uint64_t>(qid[nb]) * cap + slot] = Cand{v * inv_s[nb], row};
+            else overflow[qid[nb]] = 1u;
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two speculative stages before exit
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic corpus generator: one wave per row (bit-identical to nvdb_synth_rows_f32 on the host
+// followed by the RNE half conversion / the reference's int8 quantiser).
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void gen_rows_kernel(uint64_t seed, uint64_t row_base, uint64_t n, uint32_t dim,
+                                                       void* __restrict__ rows, float* __restrict__ scales) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const uint32_t key = synth_row_key(seed, row_base + r);
+  unsigned long long ss = 0;
+  for (uint32_t c = lane; c < dim; c += 64) { const long long v = synth_raw(key, c); ss += static_cast<unsigned long long>(v * v); }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const double inv = synth_inv_norm(ss);
+  if constexpr (DT == DT_F32) {
+    float* out = static_cast<float*>(rows) + r * dim;
+    for (uint32_t c = lane; c < dim; c += 64) out[c] = synth_elem(synth_raw(key, c), inv);
+  } else if constexpr (DT == DT_F16) {
+    _Float16* out = static_cast<_Float16*>(rows) + r * dim;
+    for (uint32_t c = lane; c < dim; c += 64) out[c] = static_cast<_Float16>(synth_elem(synth_raw(key, c), inv));
+  } else {
+    float mx = 0.f;
+    for (uint32_t c = lane; c < dim; c += 64) mx = fmaxf(mx, fabsf(synth_elem(synth_raw(key, c), inv)));
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float scale = mx > 0.f ? mx / 127.f : 1.f;
+    const float is = 1.0f / scale;
+    signed char* out = static_cast<signed char*>(rows) + r * dim;
+    for (uint32_t c = lane; c < dim; c += 64) {
+      float qv = rintf(synth_elem(synth_raw(key, c), inv) * is);
+      qv = fminf(fmaxf(qv, -127.f), 127.f);
+      out[c] = static_cast<signed char>(static_cast<int>(qv));
+    }
+    if (lane == 0) scales[r] = scale;
+  }
+}
+
+// max over rows of the (dequantised) L2 norm, slightly inflated; result as float bits via atomicMax
+template <int DT>
+__global__ __launch_bounds__(256) void row_norm_max_kernel(const void* __restrict__ rows, const float* __restrict__ scales,
+                                                           uint64_t n, uint32_t dim, uint32_t* __restrict__ out_bits) {
+  const int lane = threadIdx.x & 63;
+  float wmax = 0.f;
+  for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); r < n; r += static_cast<uint64_t>(gridDim.x) * 4) {
+    const void* rp = row_ptr<DT>(rows, r, dim);
+    float ss = 0.f;
+    for (uint32_t c = lane; c < dim; c += 64) { const float v = load1<DT>(rp, c); ss = __builtin_fmaf(v, v, ss); }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    float nrm = sqrtf(ss) * 1.0001f;
+    if constexpr (DT == DT_I8) nrm *= fabsf(scales[r]);
+    wmax = fmaxf(wmax, nrm);
+  }
+  if (lane == 0 && wmax > 0.f) atomicMax(out_bits, __builtin_bit_cast(uint32_t, wmax));
+}
+
+}  // namespace nvdbhip

@@ -1,0 +1,138 @@
+// kernels_refine.h -- exact squared-L2 rerank of R candidates per query (the stage that follows
+// IVF-PQ candidate generation).  HIP replacement for the reference's CUDA kernels
+// (src/cuda_refine.cu:405-502 and its warp-merge variants :505-838), designed for wave64:
+//
+//   * one workgroup (256 threads = 4 waves) per query, one lane per candidate row;
+//   * the query is wave-uniform, so its elements come from SGPRs (scalar loads), the candidate row
+//     is streamed with 16-byte loads;
+//   * distance arithmetic follows the reference kernel's fp32 order exactly
+//     (l2_fp16_base_half2, cuda_refine.cu:326-382: pair p -> accumulator p&3, two fmaf per pair,
+//      (a0+a1)+(a2+a3); l2_fp32_base, :383-392: one accumulator, one fma per element);
+//   * top-K is wavefront-resident (entry j in lane j, K <= 64) instead of the reference's
+//     per-thread register lists + thread-0 serial merge, which its own profile shows to be 58 % of
+//     the kernel (Performance_CUDA.md:267); the four waves' lists are merged through LDS.
+//   * ties: (distance asc, id asc).  Output padded with id 0xFFFFFFFF / dist 1e30 (:248-252, :892-894).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_exact.h"
+
+namespace nvdbhip {
+
+__device__ __forceinline__ bool closer(float d1, uint32_t i1, float d2, uint32_t i2) {
+  return (d1 < d2) || (d1 == d2 && i1 < i2);
+}
+
+struct WaveTopKMin { float d; uint32_t id; uint32_t cnt; float thr_d; uint32_t thr_id; };
+
+__device__ __forceinline__ void wmin_insert(WaveTopKMin& t, uint32_t K, float d, uint32_t id, int lane) {
+  const bool b = (static_cast<uint32_t>(lane) < t.cnt) && closer(t.d, t.id, d, id);
+  const uint32_t pos = static_cast<uint32_t>(__builtin_popcountll(__ballot(b)));
+  if (pos >= K) return;
+  const float up_d = __shfl_up(t.d, 1);
+  const uint32_t up_id = __shfl_up(t.id, 1);
+  if (static_cast<uint32_t>(lane) > pos) { t.d = up_d; t.id = up_id; }
+  else if (static_cast<uint32_t>(lane) == pos) { t.d = d; t.id = id; }
+  if (t.cnt < K) ++t.cnt;
+  if (t.cnt == K) { t.thr_d = readlane_f(t.d, static_cast<int>(K) - 1); t.thr_id = readlane_u(t.id, static_cast<int>(K) - 1); }
+}
+__device__ __forceinline__ bool wmin_accepts(const WaveTopKMin& t, uint32_t K, float d, uint32_t id) {
+  return t.cnt < K || closer(d, id, t.thr_d, t.thr_id);
+}
+
+// fp16 rows: cuda_refine.cu:326-382
+template <bool ALIGNED>
+__device__ __forceinline__ float l2_f16_ref_order(const unsigned short* __restrict__ x, const float* __restrict__ q, uint32_t dim) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const uint32_t d2 = dim >> 1;
+  uint32_t p = 0;
+#pragma unroll 2
+  for (; p + 3 < d2; p += 4) {          // 4 pairs = 8 dims per step
+    float xv[8];
+    load8<DT_F16, ALIGNED>(x, 2 * p, xv);
+    float dx, dy;
+    dx = q[2 * p + 0] - xv[0]; dy = q[2 * p + 1] - xv[1]; a0 = __builtin_fmaf(dx, dx, a0); a0 = __builtin_fmaf(dy, dy, a0);
+    dx = q[2 * p + 2] - xv[2]; dy = q[2 * p + 3] - xv[3]; a1 = __builtin_fmaf(dx, dx, a1); a1 = __builtin_fmaf(dy, dy, a1);
+    dx = q[2 * p + 4] - xv[4]; dy = q[2 * p + 5] - xv[5]; a2 = __builtin_fmaf(dx, dx, a2); a2 = __builtin_fmaf(dy, dy, a2);
+    dx = q[2 * p + 6] - xv[6]; dy = q[2 * p + 7] - xv[7]; a3 = __builtin_fmaf(dx, dx, a3); a3 = __builtin_fmaf(dy, dy, a3);
+  }
+  for (p = d2 & ~3u; p < d2; ++p) {     // leftover pairs all go to accumulator 0 (:368-376)
+    const float dx = q[2 * p] - half_bits_to_float(x[2 * p]);
+    const float dy = q[2 * p + 1] - half_bits_to_float(x[2 * p + 1]);
+    a0 = __builtin_fmaf(dx, dx, a0); a0 = __builtin_fmaf(dy, dy, a0);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+// fp32 rows: cuda_refine.cu:383-392 (`acc += diff*diff`, contracted to FMA by nvcc's default)
+template <bool ALIGNED>
+__device__ __forceinline__ float l2_f32_ref_order(const float* __restrict__ x, const float* __restrict__ q, uint32_t dim) {
+  float acc = 0.f;
+  uint32_t j = 0;
+  if constexpr (ALIGNED) {
+#pragma unroll 2
+    for (; j + 8 <= dim; j += 8) {
+      float xv[8];
+      load8<DT_F32, true>(x, j, xv);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const float d = q[j + u] - xv[u]; acc = __builtin_fmaf(d, d, acc); }
+    }
+  }
+  for (; j < dim; ++j) { const float d = q[j] - x[j]; acc = __builtin_fmaf(d, d, acc); }
+  return acc;
+}
+
+// grid = Q, block = 256.  out_dist may be null.
+template <int DT, bool ALIGNED>
+__global__ __launch_bounds__(256) void refine_l2_kernel(const void* __restrict__ rows, uint64_t n, uint32_t dim,
+                                                        const float* __restrict__ queries, const uint32_t* __restrict__ cand,
+                                                        uint32_t R, uint32_t K, uint32_t* __restrict__ out_ids,
+                                                        float* __restrict__ out_dist) {
+  __shared__ float lds_d[4][64];
+  __shared__ uint32_t lds_id[4][64];
+  __shared__ uint32_t lds_cnt[4];
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* __restrict__ qv = queries + static_cast<uint64_t>(q) * dim;
+  const uint32_t* __restrict__ cq = cand + static_cast<uint64_t>(q) * R;
+
+  WaveTopKMin tk;
+  tk.d = 1e30f; tk.id = 0xFFFFFFFFu; tk.cnt = 0; tk.thr_d = 1e30f; tk.thr_id = 0xFFFFFFFFu;
+
+  for (uint32_t r0 = wave * 64u; r0 < R; r0 += 256u) {
+    const uint32_t r = r0 + lane;
+    const uint32_t id = (r < R) ? cq[r] : 0xFFFFFFFFu;
+    const bool valid = (id != 0xFFFFFFFFu) && (static_cast<uint64_t>(id) < n);     // cuda_refine.cu:437
+    const uint32_t rid = valid ? id : 0u;
+    float d;
+    if constexpr (DT == DT_F16) d = l2_f16_ref_order<ALIGNED>(static_cast<const unsigned short*>(rows) + static_cast<uint64_t>(rid) * dim, qv, dim);
+    else d = l2_f32_ref_order<ALIGNED>(static_cast<const float*>(rows) + static_cast<uint64_t>(rid) * dim, qv, dim);
+    unsigned long long m = __ballot(valid && wmin_accepts(tk, K, d, id));
+    while (m) {
+      const int L = __builtin_ctzll(m);
+      m &= m - 1;
+      const float cd = readlane_f(d, L);
+      const uint32_t cid = readlane_u(id, L);
+      if (wmin_accepts(tk, K, cd, cid)) wmin_insert(tk, K, cd, cid, lane);
+    }
+  }
+  lds_d[wave][lane] = tk.d; lds_id[wave][lane] = tk.id;
+  if (lane == 0) lds_cnt[wave] = tk.cnt;
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w = 1; w < 4; ++w) {
+    const uint32_t c = lds_cnt[w];
+    for (uint32_t j = 0; j < c; ++j) {
+      const float cd = lds_d[w][j];
+      const uint32_t cid = lds_id[w][j];
+      if (wmin_accepts(tk, K, cd, cid)) wmin_insert(tk, K, cd, cid, lane);
+    }
+  }
+  if (static_cast<uint32_t>(lane) < K) {
+    const bool have = static_cast<uint32_t>(lane) < tk.cnt;
+    out_ids[static_cast<uint64_t>(q) * K + lane] = have ? tk.id : 0xFFFFFFFFu;
+    if (out_dist) out_dist[static_cast<uint64_t>(q) * K + lane] = have ? tk.d : 1e30f;
+  }
+}
+
+}  // namespace nvdbhip

@@ -1,0 +1,704 @@
+// nvdb_hip.cpp -- implementation of the C ABI in include/nvdb_hip.h (compiled with hipcc for gfx950).
+//
+// Orchestration of one flat search (DESIGN.md "pipeline"):
+//   path 1 (exact):   scan_exact_kernel over the whole corpus -> select(final)
+//   path 2 (filter):  prep_q16 -> scan_exact on the first chunk0 rows (threshold bootstrap)
+//                     -> select(threshold) -> { filter_f16_kernel on a chunk -> select(threshold) }*
+//                     with doubling chunks -> rescore_kernel (exact fp32 order) -> select(final)
+// There is NO CPU fallback anywhere in this file: without a working HIP device every entry point
+// that computes returns NVDB_ERR_HIP.
+#include "../../include/nvdb_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "kernels_exact.h"
+#include "kernels_filter.h"
+#include "kernels_refine.h"
+#include "nvdb_common.h"
+
+using namespace nvdbhip;
+
+namespace {
+
+std::string g_create_err;
+
+constexpr uint32_t SELECT_MAX_CAP = 8192;     // 64 KB of LDS in select_kernel
+constexpr float FILTER_REL_F16 = 7.5e-4f;     // |filter - reference| <= REL * ||q|| * max||x||   (DESIGN.md "error bound")
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct nvdb_hip_ctx {
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // resident corpus
+  void* rows = nullptr;
+  float* scales = nullptr;
+  bool owned = false;
+  uint64_t n = 0;
+  uint32_t dim = 0, dtype = 0;
+  uint64_t row_base = 0;
+  float max_norm = 0.f;
+
+  // grow-only workspace
+  DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc;
+  DevBuf rq, rcand, rout_ids, rout_dist;           // refine
+  void* pin = nullptr; size_t pin_bytes = 0;       // pinned staging
+
+  // options
+  int64_t opt_path = 0, opt_chunk0 = 4096, opt_cap = 0, opt_min_filter_batch = 16;
+
+  // state of the last search
+  nvdb_hip_scan_stats stats{};
+  uint32_t last_nq = 0, last_cap = 0;
+  bool last_filter = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<std::pair<int, int>> ev_filter;      // (start,stop) event indices of filter launches
+  std::set<const void*> lds_attr_set;              // kernels whose dynamic-LDS limit was raised on this device
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+      return NVDB_ERR_HIP;                                                                       \
+    }                                                                                            \
+  } while (0)
+
+nvdb_status fail(nvdb_hip_ctx* c, nvdb_status s, const std::string& msg) {
+  c->err = msg;
+  return s;
+}
+
+nvdb_status ensure(nvdb_hip_ctx* c, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return NVDB_OK;
+  if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+  size_t want = std::max<size_t>(bytes, 256);
+  HIPCHK(c, hipMalloc(&b.p, want));
+  b.bytes = want;
+  return NVDB_OK;
+}
+
+nvdb_status ensure_pinned(nvdb_hip_ctx* c, size_t bytes) {
+  if (c->pin_bytes >= bytes) return NVDB_OK;
+  if (c->pin) { HIPCHK(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_bytes = 0; }
+  HIPCHK(c, hipHostMalloc(&c->pin, bytes, hipHostMallocDefault));
+  c->pin_bytes = bytes;
+  return NVDB_OK;
+}
+
+size_t bpe_of(uint32_t dtype) { return dtype == NVDB_DTYPE_F32 ? 4 : (dtype == NVDB_DTYPE_F16 ? 2 : (dtype == NVDB_DTYPE_I8 ? 1 : 0)); }
+
+bool aligned_rows(uint32_t dtype, uint32_t dim) {
+  if (dtype == NVDB_DTYPE_F32) return dim % 4 == 0;
+  return dim % 8 == 0;    // f16: 16-byte groups of 8; int8: 8-byte groups of 8
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+void free_corpus(nvdb_hip_ctx* c) {
+  if (c->owned) {
+    if (c->rows) (void)hipFree(c->rows);
+    if (c->scales) (void)hipFree(c->scales);
+  }
+  c->rows = nullptr; c->scales = nullptr; c->owned = false; c->n = 0; c->dim = 0; c->dtype = 0; c->max_norm = 0.f;
+}
+
+nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
+  nvdb_status st = ensure(c, c->misc, 64);
+  if (st) return st;
+  HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 64, c->stream));
+  uint32_t* bits = static_cast<uint32_t*>(c->misc.p) + 8;
+  const unsigned grid = static_cast<unsigned>(std::min<uint64_t>((c->n + 3) / 4, 4096));
+  if (c->dtype == NVDB_DTYPE_F32) row_norm_max_kernel<DT_F32><<<grid, 256, 0, c->stream>>>(c->rows, c->scales, c->n, c->dim, bits);
+  else if (c->dtype == NVDB_DTYPE_F16) row_norm_max_kernel<DT_F16><<<grid, 256, 0, c->stream>>>(c->rows, c->scales, c->n, c->dim, bits);
+  else row_norm_max_kernel<DT_I8><<<grid, 256, 0, c->stream>>>(c->rows, c->scales, c->n, c->dim, bits);
+  HIPCHK(c, hipGetLastError());
+  uint32_t h = 0;
+  HIPCHK(c, hipMemcpyAsync(&h, bits, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(&c->max_norm, &h, 4);
+  return NVDB_OK;
+}
+
+nvdb_status check_corpus_args(nvdb_hip_ctx* c, uint64_t n, uint32_t dim, uint32_t dtype) {
+  if (!c) return NVDB_ERR_INVALID;
+  if (n == 0 || dim == 0) return fail(c, NVDB_ERR_INVALID, "corpus: count and dim must be > 0");
+  if (bpe_of(dtype) == 0) return fail(c, NVDB_ERR_INVALID, "Unsupported base dtype (Float32/Float16/Int8 only)");
+  if (n >= 0xFFFFFFF0ull) return fail(c, NVDB_ERR_UNSUPPORTED, "corpus shard must hold fewer than 2^32-16 rows (shard it)");
+  return NVDB_OK;
+}
+
+// ---- kernel launch helpers ------------------------------------------------------------------------
+
+template <int QG>
+nvdb_status launch_scan_exact_qg(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, const float* q32,
+                                 uint32_t nq, uint32_t k, const float* thr, uint32_t P, uint32_t cap) {
+  const dim3 grid(P, (nq + QG - 1) / QG);
+  Cand* cand = static_cast<Cand*>(c->cand.p);
+  uint32_t* cnt = static_cast<uint32_t*>(c->cnt.p);
+  uint32_t* ovf = static_cast<uint32_t*>(c->overflow.p);
+  const bool al = aligned_rows(c->dtype, c->dim);
+#define NVDB_LAUNCH_SCAN(DT, AL) \
+  scan_exact_kernel<DT, QG, AL><<<grid, 256, 0, s>>>(c->rows, c->scales, c->dim, row_lo, row_hi, q32, nq, 0u, k, thr, cand, cnt, cap, ovf)
+  if (c->dtype == NVDB_DTYPE_F32) { if (al) NVDB_LAUNCH_SCAN(DT_F32, true); else NVDB_LAUNCH_SCAN(DT_F32, false); }
+  else if (c->dtype == NVDB_DTYPE_F16) { if (al) NVDB_LAUNCH_SCAN(DT_F16, true); else NVDB_LAUNCH_SCAN(DT_F16, false); }
+  else { if (al) NVDB_LAUNCH_SCAN(DT_I8, true); else NVDB_LAUNCH_SCAN(DT_I8, false); }
+#undef NVDB_LAUNCH_SCAN
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+// rows [row_lo,row_hi) x all nq queries; appends at most P*k entries per query
+nvdb_status launch_scan_exact(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, const float* q32,
+                              uint32_t nq, uint32_t k, const float* thr, uint32_t cap, uint32_t reserve) {
+  const uint32_t QG = nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1));
+  const uint32_t gy = (nq + QG - 1) / QG;
+  const uint32_t rows = row_hi - row_lo;
+  uint32_t pmax = (cap > reserve + k) ? (cap - reserve) / k : 1;       // list capacity
+  uint32_t P = std::max<uint32_t>(1, (8u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);   // ~8 workgroups per CU
+  P = std::min(P, std::max<uint32_t>(1, (rows + 255) / 256));                                   // >= one 256-row sweep each
+  P = std::max<uint32_t>(1, std::min(P, pmax));
+  switch (QG) {
+    case 8: return launch_scan_exact_qg<8>(c, s, row_lo, row_hi, q32, nq, k, thr, P, cap);
+    case 4: return launch_scan_exact_qg<4>(c, s, row_lo, row_hi, q32, nq, k, thr, P, cap);
+    case 2: return launch_scan_exact_qg<2>(c, s, row_lo, row_hi, q32, nq, k, thr, P, cap);
+    default: return launch_scan_exact_qg<1>(c, s, row_lo, row_hi, q32, nq, k, thr, P, cap);
+  }
+}
+
+nvdb_status launch_select(nvdb_hip_ctx* c, hipStream_t s, uint32_t nq, uint32_t cap, uint32_t k, const float* slack,
+                          int mode, uint64_t* out_ids, float* out_scores, uint32_t out_k) {
+  const void* fn = reinterpret_cast<const void*>(select_kernel);
+  if (!c->lds_attr_set.count(fn)) {
+    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_MAX_CAP * sizeof(Cand)));
+    c->lds_attr_set.insert(fn);
+  }
+  select_kernel<<<nq, 256, cap * sizeof(Cand), s>>>(static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap, k, slack,
+                                                   static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->overflow.p), mode,
+                                                   c->row_base, reinterpret_cast<unsigned long long*>(out_ids), out_scores, out_k);
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+nvdb_status launch_rescore(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uint32_t nq, uint32_t cap) {
+  Cand* cand = static_cast<Cand*>(c->cand.p);
+  const uint32_t* cnt = static_cast<const uint32_t*>(c->cnt.p);
+  const float* eb = static_cast<const float*>(c->ebound.p);
+  uint32_t* viol = static_cast<uint32_t*>(c->misc.p);
+  unsigned long long* tot = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->misc.p) + 8);
+  const bool al = aligned_rows(c->dtype, c->dim);
+#define NVDB_LAUNCH_RS(DT, AL) rescore_kernel<DT, AL><<<nq, 256, 0, s>>>(c->rows, c->scales, c->dim, q32, cand, cnt, cap, eb, viol, tot)
+  if (c->dtype == NVDB_DTYPE_F32) { if (al) NVDB_LAUNCH_RS(DT_F32, true); else NVDB_LAUNCH_RS(DT_F32, false); }
+  else if (c->dtype == NVDB_DTYPE_F16) { if (al) NVDB_LAUNCH_RS(DT_F16, true); else NVDB_LAUNCH_RS(DT_F16, false); }
+  else { if (al) NVDB_LAUNCH_RS(DT_I8, true); else NVDB_LAUNCH_RS(DT_I8, false); }
+#undef NVDB_LAUNCH_RS
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+bool filter_supported(const nvdb_hip_ctx* c) {
+  return c->dtype == NVDB_DTYPE_F16 && (c->dim == 768 || c->dim == 384);
+}
+
+template <int DIM>
+nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
+                              uint32_t cap) {
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * DIM * 2;
+  const void* fn = reinterpret_cast<const void*>(filter_f16_kernel<DIM>);
+  if (!c->lds_attr_set.count(fn)) {
+    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    c->lds_attr_set.insert(fn);
+  }
+  uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
+  if (nwg == 0) nwg = QT;
+  filter_f16_kernel<DIM><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), row_lo, row_hi,
+                                               static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
+                                               static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
+                                               static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap,
+                                               static_cast<uint32_t*>(c->overflow.p));
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT, uint32_t cap) {
+  if (c->dim == 768) return launch_filter_dim<768>(c, s, row_lo, row_hi, nq, QT, cap);
+  if (c->dim == 384) return launch_filter_dim<384>(c, s, row_lo, row_hi, nq, QT, cap);
+  return fail(c, NVDB_ERR_UNSUPPORTED, "filter kernel: unsupported dim");
+}
+
+hipEvent_t get_event(nvdb_hip_ctx* c, size_t idx) {
+  while (c->ev_pool.size() <= idx) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
+  return c->ev_pool[idx];
+}
+
+// Enqueue one whole search of nq (<= 2048) queries resident at dev_q.  No host synchronisation.
+nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint32_t nq, uint32_t k, uint64_t* dev_out_ids,
+                        float* dev_out_scores, int force_path, bool time_filter) {
+  const uint32_t k_eff = static_cast<uint32_t>(std::min<uint64_t>(k, c->n));
+  const uint32_t n = static_cast<uint32_t>(c->n);
+  int path = force_path ? force_path : static_cast<int>(c->opt_path);
+  if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
+  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16 corpus with dim 768 or 384");
+
+  uint32_t cap = c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : (nq <= 64 ? SELECT_MAX_CAP : 2048u);
+  cap = std::min(cap, SELECT_MAX_CAP);
+  if (cap < 4 * k_eff) cap = std::min<uint32_t>(SELECT_MAX_CAP, 4 * k_eff);
+  const uint32_t QT = (nq + FILTER_QPB - 1) / FILTER_QPB;
+  const uint32_t nq_pad = QT * FILTER_QPB;
+
+  nvdb_status st;
+  if ((st = ensure(c, c->thr, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->cnt, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->overflow, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->cand, static_cast<size_t>(nq) * cap * sizeof(Cand)))) return st;
+  if ((st = ensure(c, c->misc, 64))) return st;
+  HIPCHK(c, hipMemsetAsync(c->cnt.p, 0, nq_pad * 4, s));
+  HIPCHK(c, hipMemsetAsync(c->overflow.p, 0, nq_pad * 4, s));
+  HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 16, s));
+  fill_u32_kernel<<<(nq_pad + 255) / 256, 256, 0, s>>>(static_cast<uint32_t*>(c->thr.p), 0xFF800000u, nq_pad);   // -inf
+
+  c->stats = nvdb_hip_scan_stats{};
+  c->stats.path = static_cast<uint32_t>(path);
+  c->last_nq = nq; c->last_cap = cap; c->last_filter = (path == 2);
+  c->ev_filter.clear();
+
+  if (path == 1) {
+    if ((st = launch_scan_exact(c, s, 0, n, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
+    c->stats.chunks = 1; c->stats.rows_scanned = c->n;
+    return launch_select(c, s, nq, cap, k_eff, nullptr, 1, dev_out_ids, dev_out_scores, k);
+  }
+
+  // ---- path 2: MFMA filter ----------------------------------------------------------------------
+  if ((st = ensure(c, c->q16, static_cast<size_t>(nq_pad) * c->dim * 2))) return st;
+  if ((st = ensure(c, c->qscale, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->qinv, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->ebound, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->slack, nq_pad * 4))) return st;
+  prep_q16_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->max_norm, FILTER_REL_F16, static_cast<_Float16*>(c->q16.p),
+                                         static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
+                                         static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
+  HIPCHK(c, hipGetLastError());
+  const float* slack = static_cast<const float*>(c->slack.p);
+  uint32_t r = std::min<uint32_t>(n, static_cast<uint32_t>(c->opt_chunk0));
+  if ((st = launch_scan_exact(c, s, 0, r, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
+  if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
+  uint64_t size = r;
+  size_t ev = 0;
+  while (r < n) {
+    const uint32_t hi = static_cast<uint32_t>(std::min<uint64_t>(n, static_cast<uint64_t>(r) + size));
+    if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev), s)); }
+    if ((st = launch_filter(c, s, r, hi, nq, QT, cap))) return st;
+    if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev + 1), s)); c->ev_filter.emplace_back(ev, ev + 1); ev += 2; }
+    if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
+    c->stats.chunks++;
+    c->stats.rows_scanned += static_cast<uint64_t>(hi - r) * QT;
+    r = hi;
+    size *= 2;
+  }
+  if ((st = launch_rescore(c, s, dev_q, nq, cap))) return st;
+  return launch_select(c, s, nq, cap, k_eff, nullptr, 1, dev_out_ids, dev_out_scores, k);
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int nvdb_hip_abi_version(void) { return NVDB_HIP_ABI_VERSION; }
+
+int nvdb_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+nvdb_status nvdb_hip_create(int device_ordinal, nvdb_hip_ctx** out_ctx) {
+  if (!out_ctx) return NVDB_ERR_INVALID;
+  *out_ctx = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_err = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    return NVDB_ERR_HIP;
+  }
+  if (device_ordinal < 0 || device_ordinal >= ndev) { g_create_err = "device ordinal out of range"; return NVDB_ERR_INVALID; }
+  if ((e = hipSetDevice(device_ordinal)) != hipSuccess) { g_create_err = hipGetErrorString(e); return NVDB_ERR_HIP; }
+  auto* c = new nvdb_hip_ctx();
+  c->device = device_ordinal;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_create_err = hipGetErrorString(e);
+    delete c;
+    return NVDB_ERR_HIP;
+  }
+  *out_ctx = c;
+  return NVDB_OK;
+}
+
+void nvdb_hip_destroy(nvdb_hip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_corpus(c);
+  for (DevBuf* b : {&c->q32, &c->q16, &c->qscale, &c->qinv, &c->ebound, &c->slack, &c->thr, &c->cnt, &c->overflow, &c->cand,
+                    &c->out_ids, &c->out_scores, &c->misc, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
+    if (b->p) (void)hipFree(b->p);
+  if (c->pin) (void)hipHostFree(c->pin);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* nvdb_hip_last_error(const nvdb_hip_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+nvdb_status nvdb_hip_upload_corpus(nvdb_hip_ctx* c, const void* rows, const float* scales, uint64_t n, uint32_t dim,
+                                   uint32_t dtype, uint64_t global_row_base) {
+  nvdb_status st = check_corpus_args(c, n, dim, dtype);
+  if (st) return st;
+  if (!rows) return fail(c, NVDB_ERR_INVALID, "upload_corpus: null rows");
+  if (dtype == NVDB_DTYPE_I8 && !scales) return fail(c, NVDB_ERR_INVALID, "upload_corpus: int8 corpus needs per-row scales");
+  HIPCHK(c, hipSetDevice(c->device));
+  free_corpus(c);
+  const size_t bytes = static_cast<size_t>(n) * dim * bpe_of(dtype);
+  HIPCHK(c, hipMalloc(&c->rows, bytes + 4096));     // tail padding: 16-byte vector loads never leave the allocation
+  c->owned = true;
+  const size_t chunk = size_t(256) << 20;
+  for (size_t off = 0; off < bytes; off += chunk) {
+    const size_t take = std::min(chunk, bytes - off);
+    HIPCHK(c, hipMemcpy(static_cast<char*>(c->rows) + off, static_cast<const char*>(rows) + off, take, hipMemcpyHostToDevice));
+  }
+  if (dtype == NVDB_DTYPE_I8) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), n * sizeof(float)));
+    HIPCHK(c, hipMemcpy(c->scales, scales, n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  c->n = n; c->dim = dim; c->dtype = dtype; c->row_base = global_row_base;
+  return compute_max_norm(c);
+}
+
+nvdb_status nvdb_hip_adopt_corpus(nvdb_hip_ctx* c, void* dev_rows, float* dev_scales, uint64_t n, uint32_t dim, uint32_t dtype,
+                                  uint64_t global_row_base) {
+  nvdb_status st = check_corpus_args(c, n, dim, dtype);
+  if (st) return st;
+  if (!dev_rows) return fail(c, NVDB_ERR_INVALID, "adopt_corpus: null rows");
+  if (dtype == NVDB_DTYPE_I8 && !dev_scales) return fail(c, NVDB_ERR_INVALID, "adopt_corpus: int8 corpus needs per-row scales");
+  HIPCHK(c, hipSetDevice(c->device));
+  free_corpus(c);
+  c->rows = dev_rows; c->scales = dev_scales; c->owned = false;
+  c->n = n; c->dim = dim; c->dtype = dtype; c->row_base = global_row_base;
+  return compute_max_norm(c);
+}
+
+nvdb_status nvdb_hip_generate_corpus(nvdb_hip_ctx* c, uint64_t seed, uint64_t n, uint32_t dim, uint32_t dtype,
+                                     uint64_t global_row_base) {
+  nvdb_status st = check_corpus_args(c, n, dim, dtype);
+  if (st) return st;
+  HIPCHK(c, hipSetDevice(c->device));
+  free_corpus(c);
+  const size_t bytes = static_cast<size_t>(n) * dim * bpe_of(dtype);
+  HIPCHK(c, hipMalloc(&c->rows, bytes + 4096));
+  c->owned = true;
+  if (dtype == NVDB_DTYPE_I8) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), n * sizeof(float)));
+  c->n = n; c->dim = dim; c->dtype = dtype; c->row_base = global_row_base;
+  // launch in slabs so that a single launch stays well inside the grid-size limit
+  const uint64_t slab = 1ull << 24;
+  for (uint64_t r0 = 0; r0 < n; r0 += slab) {
+    const uint64_t cntr = std::min(slab, n - r0);
+    const unsigned grid = static_cast<unsigned>((cntr + 3) / 4);
+    char* rp = static_cast<char*>(c->rows) + r0 * dim * bpe_of(dtype);
+    if (dtype == NVDB_DTYPE_F32) gen_rows_kernel<DT_F32><<<grid, 256, 0, c->stream>>>(seed, global_row_base + r0, cntr, dim, rp, nullptr);
+    else if (dtype == NVDB_DTYPE_F16) gen_rows_kernel<DT_F16><<<grid, 256, 0, c->stream>>>(seed, global_row_base + r0, cntr, dim, rp, nullptr);
+    else gen_rows_kernel<DT_I8><<<grid, 256, 0, c->stream>>>(seed, global_row_base + r0, cntr, dim, rp, c->scales + r0);
+    HIPCHK(c, hipGetLastError());
+  }
+  return compute_max_norm(c);
+}
+
+nvdb_status nvdb_hip_corpus_info(const nvdb_hip_ctx* c, uint64_t* n, uint32_t* dim, uint32_t* dtype, uint64_t* base, float* mx) {
+  if (!c) return NVDB_ERR_INVALID;
+  if (n) *n = c->n;
+  if (dim) *dim = c->dim;
+  if (dtype) *dtype = c->dtype;
+  if (base) *base = c->row_base;
+  if (mx) *mx = c->max_norm;
+  return c->rows ? NVDB_OK : NVDB_ERR_NO_CORPUS;
+}
+
+nvdb_status nvdb_hip_download_rows(nvdb_hip_ctx* c, uint64_t row0, uint64_t nrows, void* rows_out, float* scales_out) {
+  if (!c) return NVDB_ERR_INVALID;
+  if (!c->rows) return fail(c, NVDB_ERR_NO_CORPUS, "Empty base");
+  if (row0 + nrows > c->n || !rows_out) return fail(c, NVDB_ERR_INVALID, "download_rows: range out of bounds");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t rb = static_cast<size_t>(c->dim) * bpe_of(c->dtype);
+  HIPCHK(c, hipMemcpy(rows_out, static_cast<const char*>(c->rows) + row0 * rb, nrows * rb, hipMemcpyDeviceToHost));
+  if (scales_out && c->scales) HIPCHK(c, hipMemcpy(scales_out, c->scales + row0, nrows * sizeof(float), hipMemcpyDeviceToHost));
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value) {
+  if (!c || !key) return NVDB_ERR_INVALID;
+  const std::string k(key);
+  if (k == "path") { if (value < 0 || value > 2) return fail(c, NVDB_ERR_INVALID, "path must be 0,1,2"); c->opt_path = value; }
+  else if (k == "chunk0_rows") { if (value < 256) return fail(c, NVDB_ERR_INVALID, "chunk0_rows must be >= 256"); c->opt_chunk0 = value; }
+  else if (k == "cand_cap") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "cand_cap out of range"); c->opt_cap = value; }
+  else if (k == "min_filter_batch") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "min_filter_batch must be >= 1"); c->opt_min_filter_batch = value; }
+  else return fail(c, NVDB_ERR_INVALID, "unknown option: " + k);
+  return NVDB_OK;
+}
+
+static nvdb_status search_args(nvdb_hip_ctx* c, const void* q, uint32_t nq, uint32_t k, const void* oi, const void* os) {
+  if (!c) return NVDB_ERR_INVALID;
+  if (!c->rows || c->n == 0) return fail(c, NVDB_ERR_NO_CORPUS, "Empty base");
+  if (nq > 0 && k > 0 && (!q || !oi || !os)) return fail(c, NVDB_ERR_INVALID, q ? "null output" : "Null query");
+  if (k > NVDB_HIP_FLAT_KMAX) return fail(c, NVDB_ERR_INVALID, "k exceeds NVDB_HIP_FLAT_KMAX (64)");
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_search_batch_dev(nvdb_hip_ctx* c, const float* dev_q, uint32_t nq, uint32_t k, uint64_t* dev_out_ids,
+                                      float* dev_out_scores, void* hip_stream) {
+  nvdb_status st = search_args(c, dev_q, nq, k, dev_out_ids, dev_out_scores);
+  if (st) return st;
+  if (nq == 0 || k == 0) return NVDB_OK;
+  if (nq > 2048) return fail(c, NVDB_ERR_UNSUPPORTED, "search_batch_dev: at most 2048 queries per call");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+  return search_core(c, s, dev_q, nq, k, dev_out_ids, dev_out_scores, 0, false);
+}
+
+nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
+  if (!c) return NVDB_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  // caller has synchronised its stream; read the self-check words
+  std::vector<uint32_t> ovf(c->last_nq);
+  uint32_t misc[4] = {0, 0, 0, 0};
+  if (c->last_nq) HIPCHK(c, hipMemcpy(ovf.data(), c->overflow.p, c->last_nq * 4, hipMemcpyDeviceToHost));
+  if (c->misc.p) HIPCHK(c, hipMemcpy(misc, c->misc.p, 16, hipMemcpyDeviceToHost));
+  uint32_t nov = 0;
+  for (uint32_t v : ovf) nov += v ? 1u : 0u;
+  c->stats.overflow_queries = nov;
+  c->stats.bound_violations = misc[0];
+  unsigned long long tot; std::memcpy(&tot, &misc[2], 8);
+  c->stats.candidates = tot;
+  float fms = 0.f;
+  for (auto& pr : c->ev_filter) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_pool[pr.first], c->ev_pool[pr.second]) == hipSuccess) fms += ms; }
+  c->stats.filter_kernel_ms = fms;
+  if (stats) *stats = c->stats;
+  if (misc[0]) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated (bound_violations > 0)");
+  if (nov) return fail(c, NVDB_ERR_INTERNAL, "candidate list overflow: re-run these queries with option path=1");
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_t nq, uint32_t k, uint64_t* out_ids,
+                                  float* out_scores, uint32_t* out_k_eff, nvdb_hip_timing* timing) {
+  nvdb_status st = search_args(c, queries, nq, k, out_ids, out_scores);
+  if (st) return st;
+  if (timing) std::memset(timing, 0, sizeof(*timing));
+  if (out_k_eff) *out_k_eff = static_cast<uint32_t>(std::min<uint64_t>(k, c->n));
+  if (nq == 0 || k == 0) return NVDB_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t qbytes = static_cast<size_t>(nq) * c->dim * 4;
+  if ((st = ensure(c, c->q32, qbytes + 8 * static_cast<size_t>(c->dim) * 4))) return st;
+  if ((st = ensure(c, c->out_ids, static_cast<size_t>(nq) * k * 8))) return st;
+  if ((st = ensure(c, c->out_scores, static_cast<size_t>(nq) * k * 4))) return st;
+  hipEvent_t e0 = get_event(c, 60), e1 = get_event(c, 61), e2 = get_event(c, 62), e3 = get_event(c, 63);
+  HIPCHK(c, hipEventRecord(e0, s));
+  HIPCHK(c, hipMemsetAsync(static_cast<char*>(c->q32.p) + qbytes, 0, 8 * static_cast<size_t>(c->dim) * 4, s));
+  HIPCHK(c, hipMemcpyAsync(c->q32.p, queries, qbytes, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipEventRecord(e1, s));
+  nvdb_hip_scan_stats total{};
+  float filter_ms = 0.f;
+  for (uint32_t q0 = 0; q0 < nq; q0 += 1024) {
+    const uint32_t b = std::min<uint32_t>(1024, nq - q0);
+    const float* dq = static_cast<const float*>(c->q32.p) + static_cast<size_t>(q0) * c->dim;
+    uint64_t* oi = static_cast<uint64_t*>(c->out_ids.p) + static_cast<size_t>(q0) * k;
+    float* os = static_cast<float*>(c->out_scores.p) + static_cast<size_t>(q0) * k;
+    if ((st = search_core(c, s, dq, b, k, oi, os, 0, timing != nullptr))) return st;
+    HIPCHK(c, hipStreamSynchronize(s));
+    nvdb_hip_scan_stats part{};
+    nvdb_status chk = nvdb_hip_search_check(c, &part);
+    if (chk == NVDB_ERR_HIP) return chk;
+    if (chk == NVDB_ERR_INTERNAL) {
+      // self-check tripped: redo this sub-batch on the always-correct exact path (still on the GPU)
+      if ((st = search_core(c, s, dq, b, k, oi, os, 1, false))) return st;
+      HIPCHK(c, hipStreamSynchronize(s));
+    }
+    total.path = std::max(total.path, part.path);
+    total.chunks += part.chunks; total.rows_scanned += part.rows_scanned; total.candidates += part.candidates;
+    total.overflow_queries += part.overflow_queries; total.bound_violations += part.bound_violations;
+    filter_ms += part.filter_kernel_ms;
+  }
+  HIPCHK(c, hipEventRecord(e2, s));
+  HIPCHK(c, hipMemcpyAsync(out_ids, c->out_ids.p, static_cast<size_t>(nq) * k * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(out_scores, c->out_scores.p, static_cast<size_t>(nq) * k * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipEventRecord(e3, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  total.filter_kernel_ms = filter_ms;
+  c->stats = total;
+  if (timing) {
+    (void)hipEventElapsedTime(&timing->h2d_ms, e0, e1);
+    (void)hipEventElapsedTime(&timing->kernel_ms, e1, e2);
+    (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
+    timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
+    timing->threads = 256; timing->nwarps = 4; timing->K = k;
+    timing->shmem_bytes = total.path == 2 ? static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->dim * 2 : 0;
+  }
+  if (total.bound_violations) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated; results were recomputed on the exact path");
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_get_stats(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
+  if (!c || !stats) return NVDB_ERR_INVALID;
+  *stats = c->stats;
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_merge_topk_dev(nvdb_hip_ctx* c, const uint64_t* dev_ids, const float* dev_scores, uint32_t nshards,
+                                    uint32_t nq, uint32_t k, uint64_t* dev_out_ids, float* dev_out_scores, void* hip_stream) {
+  if (!c) return NVDB_ERR_INVALID;
+  if (!dev_ids || !dev_scores || !dev_out_ids || !dev_out_scores) return fail(c, NVDB_ERR_INVALID, "merge_topk: null pointer");
+  if (nshards == 0 || nq == 0 || k == 0) return NVDB_OK;
+  const uint32_t m = nshards * k;
+  if (m > 4096) return fail(c, NVDB_ERR_UNSUPPORTED, "merge_topk: nshards*k must be <= 4096");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+  const size_t lds = ((m * 4 + 15) & ~15u) + static_cast<size_t>(m) * 8;
+  merge_topk_kernel<<<nq, 256, lds, s>>>(reinterpret_cast<const unsigned long long*>(dev_ids), dev_scores, nshards, nq, k,
+                                         reinterpret_cast<unsigned long long*>(dev_out_ids), dev_out_scores);
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint32_t nshards, uint32_t nq, uint32_t k,
+                                 uint64_t* out_ids, float* out_scores) {
+  if (!ids || !scores || !out_ids || !out_scores) return NVDB_ERR_INVALID;
+  std::vector<std::pair<float, uint64_t>> v(static_cast<size_t>(nshards) * k);
+  for (uint32_t q = 0; q < nq; ++q) {
+    for (uint32_t s = 0; s < nshards; ++s)
+      for (uint32_t j = 0; j < k; ++j) {
+        const size_t src = (static_cast<size_t>(s) * nq + q) * k + j;
+        v[static_cast<size_t>(s) * k + j] = {scores[src], ids[src]};
+      }
+    std::stable_sort(v.begin(), v.end(), [](const std::pair<float, uint64_t>& a, const std::pair<float, uint64_t>& b) {
+      return a.first > b.first || (a.first == b.first && a.second < b.second);
+    });
+    for (uint32_t j = 0; j < k; ++j) { out_scores[static_cast<size_t>(q) * k + j] = v[j].first; out_ids[static_cast<size_t>(q) * k + j] = v[j].second; }
+  }
+  return NVDB_OK;
+}
+
+// ---- refine -----------------------------------------------------------------------------------------
+static nvdb_status refine_args(nvdb_hip_ctx* c, const void* q, const void* cand, uint32_t K, const void* out_ids) {
+  if (!c) return NVDB_ERR_INVALID;
+  if (!c->rows || c->n == 0) return fail(c, NVDB_ERR_NO_CORPUS, "Empty base");
+  if (c->dtype != NVDB_DTYPE_F16 && c->dtype != NVDB_DTYPE_F32)
+    return fail(c, NVDB_ERR_UNSUPPORTED, "refine supports base dtype fp16/fp32 only");
+  if (K > NVDB_HIP_REFINE_KMAX) return fail(c, NVDB_ERR_INVALID, "refine: K not supported (K<=64)");
+  if (!q || !cand || !out_ids) return fail(c, NVDB_ERR_INVALID, "refine: null pointer");
+  return NVDB_OK;
+}
+
+static nvdb_status launch_refine(nvdb_hip_ctx* c, hipStream_t s, const float* dq, const uint32_t* dc, uint32_t Q, uint32_t R,
+                                 uint32_t K, uint32_t* doi, float* dod) {
+  const bool al = aligned_rows(c->dtype, c->dim);
+  if (c->dtype == NVDB_DTYPE_F16) {
+    if (al) refine_l2_kernel<DT_F16, true><<<Q, 256, 0, s>>>(c->rows, c->n, c->dim, dq, dc, R, K, doi, dod);
+    else refine_l2_kernel<DT_F16, false><<<Q, 256, 0, s>>>(c->rows, c->n, c->dim, dq, dc, R, K, doi, dod);
+  } else {
+    if (al) refine_l2_kernel<DT_F32, true><<<Q, 256, 0, s>>>(c->rows, c->n, c->dim, dq, dc, R, K, doi, dod);
+    else refine_l2_kernel<DT_F32, false><<<Q, 256, 0, s>>>(c->rows, c->n, c->dim, dq, dc, R, K, doi, dod);
+  }
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_refine_l2_topk_dev(nvdb_hip_ctx* c, const float* dq, const uint32_t* dc, uint32_t Q, uint32_t R, uint32_t K,
+                                        uint32_t* doi, float* dod, void* hip_stream) {
+  if (c && (K == 0 || Q == 0 || R == 0)) return NVDB_OK;
+  nvdb_status st = refine_args(c, dq, dc, K, doi);
+  if (st) return st;
+  HIPCHK(c, hipSetDevice(c->device));
+  return launch_refine(c, hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream, dq, dc, Q, R, K, doi, dod);
+}
+
+nvdb_status nvdb_hip_refine_l2_topk(nvdb_hip_ctx* c, const float* queries, const uint32_t* cand_ids, uint32_t Q, uint32_t R,
+                                    uint32_t K, uint32_t* out_ids, float* out_dist, nvdb_hip_timing* timing) {
+  if (timing) std::memset(timing, 0, sizeof(*timing));
+  if (c && (K == 0 || Q == 0 || R == 0)) return NVDB_OK;       // cuda_refine.cu:853-857
+  nvdb_status st = refine_args(c, queries, cand_ids, K, out_ids);
+  if (st) return st;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t qb = static_cast<size_t>(Q) * c->dim * 4, cb = static_cast<size_t>(Q) * R * 4, ob = static_cast<size_t>(Q) * K * 4;
+  if ((st = ensure(c, c->rq, qb))) return st;
+  if ((st = ensure(c, c->rcand, cb))) return st;
+  if ((st = ensure(c, c->rout_ids, ob))) return st;
+  if ((st = ensure(c, c->rout_dist, ob))) return st;
+  hipEvent_t e0 = get_event(c, 56), e1 = get_event(c, 57), e2 = get_event(c, 58), e3 = get_event(c, 59);
+  HIPCHK(c, hipEventRecord(e0, s));
+  HIPCHK(c, hipMemcpyAsync(c->rq.p, queries, qb, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->rcand.p, cand_ids, cb, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipEventRecord(e1, s));
+  if ((st = launch_refine(c, s, static_cast<const float*>(c->rq.p), static_cast<const uint32_t*>(c->rcand.p), Q, R, K,
+                          static_cast<uint32_t*>(c->rout_ids.p), out_dist ? static_cast<float*>(c->rout_dist.p) : nullptr)))
+    return st;
+  HIPCHK(c, hipEventRecord(e2, s));
+  HIPCHK(c, hipMemcpyAsync(out_ids, c->rout_ids.p, ob, hipMemcpyDeviceToHost, s));
+  if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, c->rout_dist.p, ob, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipEventRecord(e3, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (timing) {
+    (void)hipEventElapsedTime(&timing->h2d_ms, e0, e1);
+    (void)hipEventElapsedTime(&timing->kernel_ms, e1, e2);
+    (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
+    timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
+    timing->threads = 256; timing->nwarps = 4; timing->K = K; timing->R = R;
+    timing->shmem_bytes = 4 * 64 * 8 + 16;
+  }
+  return NVDB_OK;
+}
+
+// ---- host helpers -----------------------------------------------------------------------------------
+void nvdb_synth_rows_f32(uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim, float* out) {
+  std::vector<int32_t> raw(dim);
+  for (uint64_t r = 0; r < nrows; ++r) {
+    const uint32_t key = synth_row_key(seed, row0 + r);
+    uint64_t ss = 0;
+    for (uint32_t c = 0; c < dim; ++c) { raw[c] = synth_raw(key, c); ss += static_cast<uint64_t>(static_cast<int64_t>(raw[c]) * raw[c]); }
+    const double inv = synth_inv_norm(ss);
+    for (uint32_t c = 0; c < dim; ++c) out[r * dim + c] = synth_elem(raw[c], inv);
+  }
+}
+
+void nvdb_f32_to_f16(const float* src, uint16_t* dst, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i) dst[i] = f32_to_f16_rne(src[i]);
+}
+
+void nvdb_quantize_i8_rows(const float* rows, uint64_t nrows, uint32_t dim, int8_t* out, float* scales) {
+  for (uint64_t r = 0; r < nrows; ++r) scales[r] = quantize_i8_row(rows + r * dim, dim, out + r * dim);
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(libnvdb_hip.so via nvdb_amd); the oracle (oracle/liboracle.so) and the committed golden vectors
+produced by the real reference are the checkers.
+
+Bars: ids and score BITS identical to the reference CPU path (tie groups set-wise, tests/parity.py);
+refine: ids and distance bits identical to the restated reference kernel order, and within 1e-5
+relative of the reference's CPU (double) refine.
+"""
+import numpy as np
+import pytest
+
+import nvdb_amd
+import pyoracle as po
+from golden_inputs import CASES, make_case_inputs
+from parity import assert_topk_equal
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20240613
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = nvdb_amd.HipContext(0)
+    yield c
+    c.close()
+
+
+def _as_dtype(oracle, base32, tag):
+    if tag == "f32":
+        return base32, po.DT_F32, None
+    if tag == "f16":
+        return oracle.f32_to_f16(base32), po.DT_F16, None
+    b8, sc = oracle.quantize_i8(base32)
+    return b8, po.DT_I8, sc
+
+
+def _check_against_oracle(oracle, base, dt, scales, queries, ids, sc, k, what):
+    oid, osc = oracle.flat_topk(base, dt, queries, k, scales)
+    assert ids.shape == oid.shape, f"{what}: {ids.shape} vs {oid.shape}"
+    for qi in range(len(queries)):
+        allsc = None
+
+        def score_of(i, qi=qi):
+            nonlocal allsc
+            if allsc is None:
+                allsc = oracle.scores(base, dt, queries[qi], scales)
+            return allsc[i]
+        assert_topk_equal(ids[qi], sc[qi], oid[qi], osc[qi], score_of=score_of, what=f"{what}/q{qi}")
+        # our own order is canonical: (score desc, id asc)
+        assert np.array_equal(ids[qi], oid[qi]), f"{what}/q{qi}: canonical order differs"
+
+
+# ----------------------------------------------------------------------------- generator
+@pytest.mark.parametrize("dtype", [nvdb_amd.DT_F32, nvdb_amd.DT_F16, nvdb_amd.DT_I8])
+def test_device_generator_matches_host(ctx, dtype):
+    n, d, base_row = 5000, 768, 123456789012
+    ctx.generate_corpus(SEED, n, d, dtype, row_base=base_row)
+    dev, dsc = ctx.download_rows(0, n)
+    host, hsc = nvdb_amd.synth_corpus(SEED, base_row, n, d, dtype)
+    assert np.array_equal(dev, host)
+    if dtype == nvdb_amd.DT_I8:
+        assert np.array_equal(dsc.view(np.uint32), hsc.view(np.uint32))
+    info = ctx.corpus_info()
+    assert info["n"] == n and info["dim"] == d and info["row_base"] == base_row
+    assert 0.99 < info["max_row_norm"] < 1.02
+
+
+# ----------------------------------------------------------------------------- golden cases, exact path
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("tag", ["f32", "f16", "i8"])
+def test_golden_cases_exact_path(ctx, oracle, golden, name, tag):
+    base32, queries = make_case_inputs(name)
+    k = CASES[name]["k"]
+    base, dt, scales = _as_dtype(oracle, base32, tag)
+    ctx.upload_corpus(base, dt, scales)
+    ctx.set_option("path", 1)
+    ids, sc = ctx.search_batch(queries, k)
+    ctx.set_option("path", 0)
+    assert ctx.stats()["path"] == 1
+    for variant in ("st", "omp"):
+        rids, rsc = golden[f"{name}_{tag}_{variant}_ids"], golden[f"{name}_{tag}_{variant}_scores"].view(np.float32)
+        assert ids.shape == rids.shape
+        for qi in range(len(queries)):
+            allsc = oracle.scores(base, dt, queries[qi], scales)
+            assert_topk_equal(ids[qi], sc[qi], rids[qi], rsc[qi], score_of=lambda i: allsc[i],
+                              what=f"{name}/{tag}/{variant}/q{qi}")
+    _check_against_oracle(oracle, base, dt, scales, queries, ids, sc, k, f"{name}/{tag}/oracle")
+
+
+def test_single_query_and_edge_arguments(ctx, oracle):
+    base32, queries = make_case_inputs("main768")
+    ctx.upload_corpus(base32, po.DT_F32)
+    ids, sc = ctx.search_batch(queries[0], 10)               # 1-D query
+    oid, osc = oracle.flat_topk(base32, po.DT_F32, queries[:1], 10)
+    assert np.array_equal(ids, oid) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    ids0, sc0 = ctx.search_batch(queries, 0)                 # k == 0 -> empty (flat_index.cpp:18)
+    assert ids0.shape == (len(queries), 0)
+    with pytest.raises(nvdb_amd.NvdbError):
+        ctx.search_batch(queries, 65)                        # > NVDB_HIP_FLAT_KMAX
+    idx = nvdb_amd.FlatIndexHIP(base32, po.DT_F32)
+    r = idx.search_topk_dot(queries[1], 3)
+    assert [i for i, _ in r] == oid[0:0].tolist() or len(r) == 3
+    o1, s1 = oracle.flat_topk(base32, po.DT_F32, queries[1:2], 3)
+    assert [i for i, _ in r] == o1[0].tolist() and [np.float32(s) for _, s in r] == s1[0].tolist()
+    assert idx.search_topk_dot(queries[1], 0) == []
+    with pytest.raises(RuntimeError):
+        nvdb_amd.FlatIndexHIP(np.zeros((0, 8), dtype=np.float32), po.DT_F32)   # "Empty base"
+    idx.ctx.close()
+
+
+def test_search_before_corpus_is_an_error():
+    c = nvdb_amd.HipContext(0)
+    with pytest.raises(nvdb_amd.NvdbError) as e:
+        c.search_batch(np.zeros((1, 8), dtype=np.float32), 1)
+    assert e.value.status == 4 and "Empty base" in str(e.value)
+    c.close()
+
+
+# ----------------------------------------------------------------------------- MFMA filter path
+@pytest.mark.parametrize("nq,k", [(64, 10), (300, 10), (17, 1), (256, 64)])
+def test_filter_path_f16_matches_oracle(ctx, oracle, nq, k):
+    n, d = 150000 + 13, 768                                  # ragged: not a multiple of the 32-row tile
+    ctx.generate_corpus(SEED, n, d, nvdb_amd.DT_F16)
+    base, _ = nvdb_amd.synth_corpus(SEED, 0, n, d, nvdb_amd.DT_F16)
+    queries = nvdb_amd.synth_rows_f32(SEED + 1, 0, nq, d)
+    queries[::3] = oracle.f16_to_f32(base[(np.arange(0, nq, 3) * 7919) % n]) if nq < 100 else queries[::3]
+    ctx.set_option("path", 2)
+    ids, sc = ctx.search_batch(queries, k)
+    st = ctx.stats()
+    ctx.set_option("path", 0)
+    assert st["path"] == 2 and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    assert st["chunks"] >= 4 and st["candidates"] >= nq * k
+    _check_against_oracle(oracle, base, po.DT_F16, None, queries, ids, sc, k, f"filter/nq{nq}/k{k}")
+
+
+def test_filter_path_scaled_and_skewed_queries(ctx, oracle):
+    """Query scale must not matter (per-query power-of-two prescale), nor heavy-tailed elements."""
+    n, d, nq, k = 100000, 768, 48, 10
+    ctx.generate_corpus(SEED + 5, n, d, nvdb_amd.DT_F16)
+    base, _ = nvdb_amd.synth_corpus(SEED + 5, 0, n, d, nvdb_amd.DT_F16)
+    rs = np.random.RandomState(21)
+    queries = nvdb_amd.synth_rows_f32(SEED + 6, 0, nq, d)
+    queries[:16] *= np.float32(3.7e4)
+    queries[16:32] *= np.float32(2.2e-6)
+    queries[32:, :5] *= np.float32(40.0)
+    queries[40] = 0.0                                        # zero query: every score ties at 0
+    ctx.set_option("path", 2)
+    ids, sc = ctx.search_batch(queries, k)
+    st = ctx.stats()
+    ctx.set_option("path", 0)
+    assert st["bound_violations"] == 0, st
+    _check_against_oracle(oracle, base, po.DT_F16, None, queries, ids, sc, k, "filter/scaled")
+
+
+def test_filter_path_with_exact_duplicates(ctx, oracle):
+    """Exact-score ties at the k boundary: every tied row must survive the filter; order is id asc."""
+    n, d, nq, k = 60000, 768, 32, 10
+    base, _ = nvdb_amd.synth_corpus(SEED + 9, 0, n, d, nvdb_amd.DT_F16)
+    base = base.copy()
+    rs = np.random.RandomState(4)
+    for src in rs.randint(0, n, size=40):                    # 40 rows, each copied to 7 other places
+        base[rs.randint(0, n, size=7)] = base[src]
+    queries = oracle.f16_to_f32(base[rs.randint(0, n, size=nq)])
+    ctx.upload_corpus(base, po.DT_F16)
+    for path in (1, 2):
+        ctx.set_option("path", path)
+        ids, sc = ctx.search_batch(queries, k)
+        assert ctx.stats()["bound_violations"] == 0
+        _check_against_oracle(oracle, base, po.DT_F16, None, queries, ids, sc, k, f"dups/path{path}")
+    ctx.set_option("path", 0)
+
+
+def test_filter_and_exact_paths_agree_on_reference_dim_384(ctx, oracle):
+    n, d, nq, k = 80000, 384, 40, 10                         # the reference's own data dimension
+    ctx.generate_corpus(SEED + 2, n, d, nvdb_amd.DT_F16)
+    base, _ = nvdb_amd.synth_corpus(SEED + 2, 0, n, d, nvdb_amd.DT_F16)
+    queries = nvdb_amd.synth_rows_f32(SEED + 3, 0, nq, d)
+    res = {}
+    for path in (1, 2):
+        ctx.set_option("path", path)
+        res[path] = ctx.search_batch(queries, k)
+        assert ctx.stats()["path"] == path
+    ctx.set_option("path", 0)
+    assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1].view(np.uint32), res[2][1].view(np.uint32))
+    _check_against_oracle(oracle, base, po.DT_F16, None, queries, res[2][0], res[2][1], k, "dim384")
+
+
+def test_overflow_falls_back_to_exact_path(ctx, oracle):
+    """Adversarial order (rows sorted by score ascending for the query) overflows the candidate
+    lists; the library must notice and still return the exact answer."""
+    n, d, k = 40000, 768, 10
+    base32 = nvdb_amd.synth_rows_f32(SEED + 11, 0, n, d)
+    q = nvdb_amd.synth_rows_f32(SEED + 12, 0, 16, d)
+    order = np.argsort(base32 @ q[0])                        # ascending similarity to query 0
+    base = oracle.f32_to_f16(base32[order])
+    ctx.upload_corpus(base, po.DT_F16)
+    ctx.set_option("path", 2)
+    ctx.set_option("cand_cap", 64)
+    ids, sc = ctx.search_batch(q, k)
+    st = ctx.stats()
+    ctx.set_option("cand_cap", 0)
+    ctx.set_option("path", 0)
+    assert st["overflow_queries"] >= 1
+    _check_against_oracle(oracle, base, po.DT_F16, None, q, ids, sc, k, "overflow")
+
+
+# ----------------------------------------------------------------------------- sharding (multi-GPU logic on one GPU)
+def test_row_sharded_search_merges_to_the_unsharded_answer(oracle):
+    n, d, nq, k, shards = 120000, 768, 24, 10, 3
+    full = nvdb_amd.HipContext(0)
+    full.generate_corpus(SEED + 20, n, d, nvdb_amd.DT_F16)
+    queries = nvdb_amd.synth_rows_f32(SEED + 21, 0, nq, d)
+    fi, fs = full.search_batch(queries, k)
+    parts_i, parts_s = [], []
+    for s in range(shards):
+        lo, hi = n * s // shards, n * (s + 1) // shards
+        c = nvdb_amd.HipContext(0)
+        c.generate_corpus(SEED + 20, hi - lo, d, nvdb_amd.DT_F16, row_base=lo)   # global ids = base + local
+        i, sc = c.search_batch(queries, k)
+        parts_i.append(i)
+        parts_s.append(sc)
+        c.close()
+    mi, ms = nvdb_amd.merge_topk_host(np.stack(parts_i), np.stack(parts_s))
+    assert np.array_equal(mi, fi) and np.array_equal(ms.view(np.uint32), fs.view(np.uint32))
+    full.close()
+
+
+def test_device_merge_matches_host_merge(ctx):
+    import ctypes
+    rs = np.random.RandomState(8)
+    S, nq, k = 8, 50, 10
+    sc = np.sort(rs.rand(S, nq, k).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    sc[:, :, 3] = sc[:, :, 2]                                 # ties inside and across shards
+    sc[1] = sc[0]
+    ids = (rs.permutation(S * nq * k).astype(np.uint64)).reshape(S, nq, k)
+    hi, hs = nvdb_amd.merge_topk_host(ids, sc)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    bufs = []
+
+    def dev(arr):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), arr.nbytes) == 0
+        assert hip.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0
+        bufs.append(p)
+        return p
+    d_ids, d_sc = dev(ids), dev(sc)
+    oi, os_ = np.zeros((nq, k), dtype=np.uint64), np.zeros((nq, k), dtype=np.float32)
+    d_oi, d_os = dev(oi), dev(os_)
+    ctx.merge_topk_dev(d_ids, d_sc, S, nq, k, d_oi, d_os)
+    assert hip.hipDeviceSynchronize() == 0
+    assert hip.hipMemcpy(oi.ctypes.data, d_oi, oi.nbytes, 2) == 0 and hip.hipMemcpy(os_.ctypes.data, d_os, os_.nbytes, 2) == 0
+    assert np.array_equal(oi, hi) and np.array_equal(os_.view(np.uint32), hs.view(np.uint32))
+    for p in bufs:
+        hip.hipFree(p)
+
+
+# ----------------------------------------------------------------------------- refine
+@pytest.mark.parametrize("tag,d,R,K", [("f16", 768, 1024, 10), ("f16", 384, 500, 10), ("f32", 768, 300, 64),
+                                       ("f16", 100, 77, 5), ("f32", 37, 40, 3)])
+def test_refine_matches_restated_reference_order(ctx, oracle, tag, d, R, K):
+    n, Q = 30000, 40
+    rs = np.random.RandomState(d + R)
+    base32 = nvdb_amd.synth_rows_f32(SEED + 30, 0, n, d)
+    base, dt = (oracle.f32_to_f16(base32), po.DT_F16) if tag == "f16" else (base32, po.DT_F32)
+    queries = nvdb_amd.synth_rows_f32(SEED + 31, 0, Q, d)
+    cand = rs.randint(0, n, size=(Q, R)).astype(np.uint32)
+    cand[rs.rand(Q, R) < 0.01] = 0xFFFFFFFF                 # skipped slots (nvdb_ivf_eval.cpp:513-516)
+    cand[0, 1] = n + 5                                      # out of range -> skipped (cuda_refine.cu:437)
+    cand[1, :] = 0xFFFFFFFF                                 # no valid candidate at all -> all padding
+    cand[2, 5:] = 0xFFFFFFFF                                # fewer valid candidates than K (when K > 5)
+    cand[3, 10:20] = cand[3, 0]                             # duplicates of one id stay separate entries
+    ctx.upload_corpus(base, dt)
+    ids, dist, t = ctx.refine_l2_topk(queries, cand, K, want_timing=True)
+    oid, odist = oracle.refine(base, dt, queries, cand, K, mode=0)
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+    assert (ids[1] == 0xFFFFFFFF).all() and (dist[1] == np.float32(1e30)).all()
+    # against the reference's CPU refine (double accumulation): distances to fp32 rounding
+    cid, cdist = oracle.refine(base, dt, queries, cand, K, mode=1)
+    valid = ids != 0xFFFFFFFF
+    assert np.allclose(dist[valid], cdist[valid], rtol=1e-5, atol=1e-7)
+    assert t.K == K and t.R == R and t.kernel_ms > 0 and abs(t.total_ms - (t.h2d_ms + t.kernel_ms + t.d2h_ms)) < 1e-3
+    ids_only, none = ctx.refine_l2_topk(queries, cand, K, want_dist=False)   # CUDA_RETURN_DIST=0
+    assert none is None and np.array_equal(ids_only, ids)
+
+
+def test_refine_argument_conventions(ctx, oracle):
+    base = oracle.f32_to_f16(nvdb_amd.synth_rows_f32(SEED, 0, 1000, 64))
+    ctx.upload_corpus(base, po.DT_F16)
+    q = nvdb_amd.synth_rows_f32(SEED + 1, 0, 2, 64)
+    ids, dist = ctx.refine_l2_topk(q, np.zeros((2, 0), dtype=np.uint32), 10)      # R == 0 -> nothing to do
+    assert (ids == 0xFFFFFFFF).all()
+    with pytest.raises(nvdb_amd.NvdbError):
+        ctx.refine_l2_topk(q, np.zeros((2, 4), dtype=np.uint32), 65)             # K > 64 (cuda_refine.cu:858-862)
+    b8, sc = oracle.quantize_i8(nvdb_amd.synth_rows_f32(SEED, 0, 100, 64))
+    ctx.upload_corpus(b8, po.DT_I8, sc)
+    with pytest.raises(nvdb_amd.NvdbError):
+        ctx.refine_l2_topk(q, np.zeros((2, 4), dtype=np.uint32), 3)              # int8 base unsupported (nvdb_ivf_eval.cpp:519-525)
