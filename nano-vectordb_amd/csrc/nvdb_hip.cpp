@@ -301,13 +301,16 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
                                          static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
   HIPCHK(c, hipGetLastError());
   const float* slack = static_cast<const float*>(c->slack.p);
-  uint32_t r = std::min<uint32_t>(n, static_cast<uint32_t>(c->opt_chunk0));
+  // bootstrap chunk [0,r) on the exact kernel; r is a multiple of the 32-row MFMA tile so that every
+  // filter chunk [r,hi) is whole tiles; the ragged tail [n_al,n) also goes to the exact kernel.
+  uint32_t r = std::min<uint32_t>(n, (static_cast<uint32_t>(c->opt_chunk0) + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS);
+  const uint32_t n_al = (n <= r) ? n : r + (n - r) / FILTER_ROWS * FILTER_ROWS;
   if ((st = launch_scan_exact(c, s, 0, r, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
   if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
   uint64_t size = r;
   size_t ev = 0;
-  while (r < n) {
-    const uint32_t hi = static_cast<uint32_t>(std::min<uint64_t>(n, static_cast<uint64_t>(r) + size));
+  while (r < n_al) {
+    const uint32_t hi = static_cast<uint32_t>(std::min<uint64_t>(n_al, static_cast<uint64_t>(r) + size));
     if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev), s)); }
     if ((st = launch_filter(c, s, r, hi, nq, QT, cap))) return st;
     if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev + 1), s)); c->ev_filter.emplace_back(ev, ev + 1); ev += 2; }
@@ -316,6 +319,10 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     c->stats.rows_scanned += static_cast<uint64_t>(hi - r) * QT;
     r = hi;
     size *= 2;
+  }
+  if (n_al < n) {   // ragged tail: exact scores, pruned by the current thresholds
+    if ((st = launch_scan_exact(c, s, n_al, n, dev_q, nq, k_eff, static_cast<const float*>(c->thr.p), cap, 0))) return st;
+    c->stats.rows_scanned += static_cast<uint64_t>(n - n_al) * QT;
   }
   if ((st = launch_rescore(c, s, dev_q, nq, cap))) return st;
   return launch_select(c, s, nq, cap, k_eff, nullptr, 1, dev_out_ids, dev_out_scores, k);
