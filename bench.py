@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: flat-scan top-10, d=768, fp16 corpus, batch 1024 (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: 1024 fp32 queries (already in HBM) against the
+resident corpus -> exact top-10 (ids + scores) in HBM.  With N GPUs the SAME corpus is row-sharded
+(rows [r*N_rows/N, (r+1)*N_rows/N) on rank r, global ids = shard base + local row), every rank scans
+its shard for the whole batch, the per-shard top-k lists are exchanged with one RCCL all-gather and
+merged on every rank (total work fixed -> "scaling": "strong").
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
+the MFMA filter kernel, timed live with HIP events on its stream) and `cpu_baseline` (the real
+reference's AVX2+OpenMP FlatIndexOMP from oracle/_ref on this box's host cores, bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+SEED = 20240613
+PEAK_F16_TFLOPS = 2500.0     # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_I8_TOPS = 5000.0        # int8 MFMA = 2x the bf16 rate per clock (same guide, "Matrix cores")
+PEAK_HBM_GBPS = 8000.0       # HBM3E 8 TB/s spec (same guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows (all GPUs together)")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--dtype", default="f16", choices=["f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=96)
+    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 exact kernel, 2 MFMA filter")
+    ap.add_argument("--sweep", default="", help="comma list of extra batch sizes to time (N=1 only), e.g. 1,16,64,256")
+    return ap.parse_args()
+
+
+def host_cpu_share():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota, by
+    NVDB_CPU_THREADS if set, and by 16 per visible GPU (the GPU box's stated CPU share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(np.ceil(q / p))))
+        except Exception:
+            pass
+    if os.environ.get("NVDB_CPU_THREADS"):
+        return max(1, int(os.environ["NVDB_CPU_THREADS"]))
+    return min(n, 16)
+
+
+def cpu_baseline(ctx, args, nvdb_amd):
+    """Time the reference's AVX2+OpenMP path (FlatIndexOMP, per query) on a bounded sample."""
+    import pyoracle as po
+    cores = host_cpu_share()
+    n_s, nq_s = min(args.cpu_sample_rows, args.rows), args.cpu_sample_queries
+    rows, _ = ctx.download_rows(0, n_s)                       # same synthetic rows the GPU scans
+    queries = nvdb_amd.synth_rows_f32(SEED + 1, 0, nq_s, args.dim)
+    scale = n_s / float(args.rows)
+    if po.Reference.available():
+        ref = po.Reference()
+        tmp = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"nvdb_bench_{os.getpid()}.vecbin")
+        try:
+            po.write_vecbin(tmp, rows, po.DT_F16)
+            h = ref.open(tmp)
+            ref.flat_search(h, queries[:4], args.k, mode=1, threads=cores, want_results=False)        # warm-up
+            _, _, ms = ref.flat_search(h, queries, args.k, mode=1, threads=cores, want_results=False)
+            ref.close(h)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        kind = "reference"
+    else:
+        orc = po.Oracle()
+        t0 = time.time()
+        for q in queries:
+            orc.flat_topk_omp(rows, po.DT_F16, q, args.k, cores)
+        ms = (time.time() - t0) * 1e3
+        kind = "port"
+    qps_sample = nq_s / (ms * 1e-3)
+    return {"value": qps_sample * scale, "unit": "queries/s", "cores": cores, "kind": kind,
+            "sample": f"{nq_s} queries, one at a time (FlatIndexOMP, {cores} OpenMP threads) over the first {n_s} rows of the same "
+                      f"fp16 corpus: {qps_sample:.2f} queries/s measured ({n_s * args.dim * 2 * qps_sample / 1e9:.1f} GB/s), "
+                      f"scaled by {n_s}/{args.rows} rows"}
+
+
+def main():
+    args = parse()
+    import torch
+    import nvdb_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    dt = nvdb_amd.DT_F16
+    N, B, D, K = args.rows, args.batch, args.dim, args.k
+    lo, hi = N * rank // world, N * (rank + 1) // world
+    ctx = nvdb_amd.HipContext(local_rank)
+    ctx.generate_corpus(SEED, hi - lo, D, dt, row_base=lo)     # one-time, excluded like the reference's base H2D
+    ctx.set_option("path", args.path)
+
+    # query batches: independent synthetic rows (no self-match), resident in HBM before timing
+    nbatches = 4
+    qhost = nvdb_amd.synth_rows_f32(SEED + 1, 0, nbatches * B, D)
+    qdev = torch.from_numpy(qhost).to(dev).contiguous()
+    out_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
+    out_sc = torch.empty((B, K), dtype=torch.float32, device=dev)
+    if world > 1:
+        g_ids = torch.empty((world, B, K), dtype=torch.int64, device=dev)
+        g_sc = torch.empty((world, B, K), dtype=torch.float32, device=dev)
+        m_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
+        m_sc = torch.empty((B, K), dtype=torch.float32, device=dev)
+
+    def step(i, batch=B):
+        stream = torch.cuda.current_stream().cuda_stream
+        q = qdev[(i % nbatches) * B:(i % nbatches) * B + batch]
+        ctx.search_batch_dev(q.data_ptr(), batch, K, out_ids.data_ptr(), out_sc.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(g_ids, out_ids)       # RCCL over xGMI: B*k*(8+4) bytes per rank
+            dist.all_gather_into_tensor(g_sc, out_sc)
+            ctx.merge_topk_dev(g_ids.data_ptr(), g_sc.data_ptr(), world, batch, K, m_ids.data_ptr(), m_sc.data_ptr(), stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- untimed: warm-up + parity self-check ---------------------------------------------------------
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    st = ctx.search_check()                                    # raises on overflow / bound violation
+    parity = "skipped"
+    if rank == 0:
+        # the filter path must reproduce the exact kernel bit for bit, and the returned scores must be
+        # the reference's CPU scores of the returned rows (oracle dot on rows copied back from HBM)
+        import pyoracle as po
+        orc = po.Oracle()
+        step(0)
+        torch.cuda.synchronize()
+        fi, fs = out_ids[:8].cpu().numpy().astype(np.uint64), out_sc[:8].cpu().numpy()
+        ctx.set_option("path", 1)
+        ctx.search_batch_dev(qdev[:8].data_ptr(), 8, K, out_ids.data_ptr(), out_sc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ei, es = out_ids[:8].cpu().numpy().astype(np.uint64), out_sc[:8].cpu().numpy()
+        ctx.set_option("path", args.path)
+        ok = np.array_equal(fi, ei) and np.array_equal(fs.view(np.uint32), es.view(np.uint32))
+        for qi in range(4):
+            for j in range(K):
+                row, _ = ctx.download_rows(int(fi[qi, j]) - lo, 1)
+                s = orc.lib.oracle_dot_f32_f16base(po._p(qhost[qi], po._f32p), row.ctypes.data, D)
+                ok = ok and np.float32(s).view(np.uint32) == fs[qi, j].view(np.uint32)
+        parity = "ok" if ok else "FAILED"
+        if not ok:
+            raise SystemExit("parity self-check failed: filter path != exact path / oracle scores")
+    barrier()
+
+    # ---- timed region ---------------------------------------------------------------------------------
+    ctx.set_option("time_kernels", 1)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.set_option("time_kernels", 0)
+    kt = ctx.collect_kernel_times()
+    stats = ctx.search_check()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    qps = args.steps * B / elapsed
+    ms_per_step = elapsed * 1e3 / args.steps
+    out = {
+        "metric": "QPS + effective HBM GB/s, flat-scan top-10 d=768",
+        "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"fp16 flat-scan top-{K}, N={N} d={D}, batch={B}", "rows_total": N,
+                   "rows_per_gpu": hi - lo, "batch": B, "k": K, "dim": D,
+                   "parallelism": "1 GPU" if world == 1 else f"corpus row-sharded x{world}, RCCL all-gather of per-shard top-k"},
+        "effective_hbm_GBps": (N * D * 2 / 1e9) / (ms_per_step * 1e-3),        # corpus bytes / pass time, all GPUs
+        "parity": parity,
+        "scan": {"path": stats["path"], "chunks": stats["chunks"], "candidates_per_query": stats["candidates"] / max(B, 1),
+                 "bound_violations": stats["bound_violations"], "overflow_queries": stats["overflow_queries"]},
+    }
+    if kt["launches"]:
+        sec = kt["ms"] * 1e-3
+        ach = kt["flops"] / sec / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS,
+                           "traffic": None, "kernel": "filter_f16_kernel<768>", "launches": kt["launches"],
+                           "avg_launch_ms": kt["ms"] / kt["launches"], "kernel_time_share": kt["ms"] / (elapsed * 1e3),
+                           "hbm_GBps_algorithmic": kt["bytes"] / sec / 1e9, "hbm_frac": kt["bytes"] / sec / 1e9 / PEAK_HBM_GBPS}
+    else:
+        out["roofline"] = None
+
+    # ---- optional batch sweep (HBM-bound points), N=1 only ---------------------------------------------
+    if args.sweep and world == 1:
+        sweep = []
+        for b in [int(x) for x in args.sweep.split(",") if x]:
+            b = min(b, B)
+            for i in range(2):
+                step(i, b)
+            ctx.set_option("time_kernels", 1)
+            barrier()
+            t0 = time.perf_counter()
+            reps = max(2, min(args.steps, 8))
+            for i in range(reps):
+                step(i, b)
+            barrier()
+            el = time.perf_counter() - t0
+            ctx.set_option("time_kernels", 0)
+            k2 = ctx.collect_kernel_times()
+            s2 = ctx.search_check()
+            sweep.append({"batch": b, "qps": reps * b / el, "ms_per_pass": el * 1e3 / reps, "path": s2["path"],
+                          "hbm_GBps": N * D * 2 / 1e9 / (el / reps), "hbm_frac": N * D * 2 / 1e9 / (el / reps) / PEAK_HBM_GBPS,
+                          "tflops": 2.0 * b * N * D / (el / reps) / 1e12,
+                          "filter_kernel_ms_per_pass": (k2["ms"] / reps) if k2["launches"] else None})
+        out["sweep"] = sweep
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(ctx, args, nvdb_amd)
+        except Exception as e:                                   # never let the baseline leg kill the bench line
+            out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": host_cpu_share(), "kind": "error",
+                                   "sample": repr(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

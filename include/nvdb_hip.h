@@ -152,9 +152,16 @@ nvdb_status nvdb_hip_merge_topk_dev(nvdb_hip_ctx* ctx, const uint64_t* dev_ids, 
 nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint32_t nshards, uint32_t nq,
                                  uint32_t k, uint64_t* out_ids, float* out_scores);
 
-/* Tunables: "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "cand_cap", "min_filter_batch".
+/* Tunables: "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "cand_cap", "min_filter_batch",
+ * "time_kernels" (1: bracket every launch of the dominant kernel with hipEvents on its stream).
  * Unknown key -> NVDB_ERR_INVALID. */
 nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* ctx, const char* key, int64_t value);
+
+/* With "time_kernels" = 1: sum of the hipEvent durations of the dominant (filter) kernel's launches
+ * since the last call, with their algorithmic flops (2 * queries * rows * dim) and corpus bytes
+ * (rows * dim * bytes/elem).  Synchronises on the recorded events.  bench.py's roofline uses it. */
+nvdb_status nvdb_hip_collect_kernel_times(nvdb_hip_ctx* ctx, uint32_t* launches, double* total_ms,
+                                          double* total_flops, double* total_bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * exact-L2 refine (rerank of R candidates per query) -- replaces nvdb::cuda_l2_topk_batch

@@ -68,7 +68,11 @@ struct nvdb_hip_ctx {
   uint32_t last_nq = 0, last_cap = 0;
   bool last_filter = false;
   std::vector<hipEvent_t> ev_pool;
-  std::vector<std::pair<int, int>> ev_filter;      // (start,stop) event indices of filter launches
+  std::vector<std::pair<int, int>> ev_filter;      // (start,stop) event indices of filter launches (last search)
+  // kernel-time accounting across searches ("time_kernels" option): one entry per dominant-kernel launch
+  struct KLaunch { hipEvent_t e0, e1; double flops, bytes; };
+  std::vector<KLaunch> klaunch;
+  int64_t opt_time_kernels = 0;
   std::set<const void*> lds_attr_set;              // kernels whose dynamic-LDS limit was raised on this device
 };
 
@@ -311,9 +315,18 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   size_t ev = 0;
   while (r < n_al) {
     const uint32_t hi = static_cast<uint32_t>(std::min<uint64_t>(n_al, static_cast<uint64_t>(r) + size));
+    nvdb_hip_ctx::KLaunch kl{nullptr, nullptr, 0.0, 0.0};
+    const bool acct = c->opt_time_kernels && c->klaunch.size() < 8192;
+    if (acct) {
+      HIPCHK(c, hipEventCreate(&kl.e0)); HIPCHK(c, hipEventCreate(&kl.e1));
+      kl.flops = 2.0 * nq * static_cast<double>(hi - r) * c->dim;          // algorithmic: real queries only
+      kl.bytes = static_cast<double>(hi - r) * c->dim * 2.0;               // corpus rows read once
+      HIPCHK(c, hipEventRecord(kl.e0, s));
+    }
     if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev), s)); }
     if ((st = launch_filter(c, s, r, hi, nq, QT, cap))) return st;
     if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev + 1), s)); c->ev_filter.emplace_back(ev, ev + 1); ev += 2; }
+    if (acct) { HIPCHK(c, hipEventRecord(kl.e1, s)); c->klaunch.push_back(kl); }
     if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
     c->stats.chunks++;
     c->stats.rows_scanned += static_cast<uint64_t>(hi - r) * QT;
@@ -375,6 +388,7 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
     if (b->p) (void)hipFree(b->p);
   if (c->pin) (void)hipHostFree(c->pin);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  for (auto& k : c->klaunch) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -471,6 +485,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   if (k == "path") { if (value < 0 || value > 2) return fail(c, NVDB_ERR_INVALID, "path must be 0,1,2"); c->opt_path = value; }
   else if (k == "chunk0_rows") { if (value < 256) return fail(c, NVDB_ERR_INVALID, "chunk0_rows must be >= 256"); c->opt_chunk0 = value; }
   else if (k == "cand_cap") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "cand_cap out of range"); c->opt_cap = value; }
+  else if (k == "time_kernels") { c->opt_time_kernels = value ? 1 : 0; }
   else if (k == "min_filter_batch") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "min_filter_batch must be >= 1"); c->opt_min_filter_batch = value; }
   else return fail(c, NVDB_ERR_INVALID, "unknown option: " + k);
   return NVDB_OK;
@@ -574,6 +589,27 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     timing->shmem_bytes = total.path == 2 ? static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->dim * 2 : 0;
   }
   if (total.bound_violations) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated; results were recomputed on the exact path");
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_collect_kernel_times(nvdb_hip_ctx* c, uint32_t* launches, double* total_ms, double* total_flops,
+                                          double* total_bytes) {
+  if (!c) return NVDB_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  double ms = 0, fl = 0, by = 0;
+  uint32_t cnt = 0;
+  for (auto& k : c->klaunch) {
+    float t = 0.f;
+    HIPCHK(c, hipEventSynchronize(k.e1));
+    HIPCHK(c, hipEventElapsedTime(&t, k.e0, k.e1));
+    ms += t; fl += k.flops; by += k.bytes; ++cnt;
+    (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1);
+  }
+  c->klaunch.clear();
+  if (launches) *launches = cnt;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (total_bytes) *total_bytes = by;
   return NVDB_OK;
 }
 
