@@ -128,7 +128,8 @@ def main():
 
     dt = nvdb_amd.DT_F16
     N, B, D, K = args.rows, args.batch, args.dim, args.k
-    lo, hi = N * rank // world, N * (rank + 1) // world
+    from nvdb_amd.sharding import shard_range
+    lo, hi = shard_range(N, rank, world)
     ctx = nvdb_amd.HipContext(local_rank)
     ctx.generate_corpus(SEED, hi - lo, D, dt, row_base=lo)     # one-time, excluded like the reference's base H2D
     ctx.set_option("path", args.path)
@@ -140,8 +141,8 @@ def main():
     out_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
     out_sc = torch.empty((B, K), dtype=torch.float32, device=dev)
     if world > 1:
-        g_ids = torch.empty((world, B, K), dtype=torch.int64, device=dev)
-        g_sc = torch.empty((world, B, K), dtype=torch.float32, device=dev)
+        g_ids = torch.empty((world * B, K), dtype=torch.int64, device=dev)      # [W][B][K], concatenated along dim 0
+        g_sc = torch.empty((world * B, K), dtype=torch.float32, device=dev)
         m_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
         m_sc = torch.empty((B, K), dtype=torch.float32, device=dev)
 

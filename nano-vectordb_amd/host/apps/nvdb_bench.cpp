@@ -1,0 +1,161 @@
+// nvdb_bench -- flat-scan benchmark CLI with the reference's arguments and output lines
+// (apps/nvdb_bench.cpp:254-425) plus mode=gpu (alias hip): the MI355X path through nvdb::FlatIndexHIP.
+//
+//   nvdb_bench <base.vecbin> <query.vecbin> <k> [mode=st] [threads=0] [warmup=5] [batch_q=1] [tile_vecs=1024] [prefetch_dist=0]
+//
+// mode: st | omp  (CPU, per query; batch_q > 1 = bench-side batching as in the reference)
+//       gpu | hip (GPU; batch_q = queries per nvdb_hip_search_batch call; tile_vecs/prefetch_dist are
+//                  accepted and echoed but have no meaning on the GPU)
+// async/pool (alternative CPU threading of the same arithmetic) are not provided: exit code 3.
+// Every line the reference prints is printed unchanged; GPU-only lines are appended after them.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <iomanip>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "nvdb/flat_index.h"
+#include "nvdb/flat_index_hip.h"
+#include "nvdb/simd_dot.h"
+
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
+using Clock = std::chrono::steady_clock;
+static double ms_between(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+int main(int argc, char** argv) {
+  if (argc < 4) {
+    std::cerr << "Usage: nvdb_bench <base.vecbin> <query.vecbin> <k> [mode=st] [threads=0] [warmup=5] [batch_q=1] [tile_vecs=1024] [prefetch_dist=0]\n";
+    return 1;
+  }
+  const std::string base_path = argv[1], query_path = argv[2];
+  const uint32_t k = static_cast<uint32_t>(std::stoul(argv[3]));
+  const std::string mode = argc >= 5 ? argv[4] : "st";
+  int threads = argc >= 6 ? std::stoi(argv[5]) : 0;
+  const int warmup = argc >= 7 ? std::stoi(argv[6]) : 5;
+  const int batch_q = argc >= 8 ? std::stoi(argv[7]) : 1;
+  const int tile_vecs = argc >= 9 ? std::stoi(argv[8]) : 1024;
+  const int prefetch_dist = argc >= 10 ? std::stoi(argv[9]) : 0;
+  const bool gpu = (mode == "gpu" || mode == "hip");
+
+  if (threads <= 0) threads = static_cast<int>(std::thread::hardware_concurrency());
+  int report_threads = threads;
+#if defined(_OPENMP)
+  if (mode == "omp") { if (argc >= 6 && std::stoi(argv[5]) > 0) omp_set_num_threads(threads); report_threads = omp_get_max_threads(); }
+#endif
+  std::cout << "mode=" << mode << " threads=" << report_threads << "\n";
+  if (const char* fs = std::getenv("NVDB_FORCE_SCALAR")) if (fs[0] == '1') nvdb::set_force_scalar(true);
+
+  nvdb::VectorDataset base, query;
+  base.load(base_path);
+  query.load(query_path);
+  if (base.dim() != query.dim()) {
+    std::cerr << "Dim mismatch: base.dim=" << base.dim() << ", query.dim=" << query.dim() << "\n";
+    return 2;
+  }
+  if (!gpu && mode != "st" && mode != "omp") { std::cerr << "Unknown or unsupported mode: " << mode << " (st|omp|gpu)\n"; return 3; }
+
+  nvdb::FlatIndex st_index(&base);
+  nvdb::FlatIndexOMP omp_index(&base);
+  std::unique_ptr<nvdb::FlatIndexHIP> hip_index;
+  if (gpu) hip_index = std::make_unique<nvdb::FlatIndexHIP>(&base, 0);    // one-time upload, not timed (like the reference's base H2D)
+
+  auto run_query = [&](const float* q) {
+    if (gpu) return hip_index->search_topk_dot(q, k);
+    return mode == "omp" ? omp_index.search_topk_dot(q, k) : st_index.search_topk_dot(q, k);
+  };
+
+  const uint64_t Q = query.count();
+  std::cout << "Base count=" << base.count() << " dim=" << base.dim() << " | Query count=" << Q << " | k=" << k << " | warmup=" << warmup << "\n";
+  for (int i = 0; i < warmup; ++i) (void)run_query(query.vector_ptr(0));
+
+  std::vector<double> lat;
+  lat.reserve(Q);
+  volatile float sink = 0.f;
+  double gpu_kernel_ms = 0.0;
+  const auto t_all0 = Clock::now();
+  if (batch_q > 1) {
+    const uint32_t dim = base.dim(), dt = base.dtype();
+    for (uint64_t q0 = 0; q0 < Q; q0 += static_cast<uint64_t>(batch_q)) {
+      const uint32_t b = static_cast<uint32_t>(std::min<uint64_t>(batch_q, Q - q0));
+      const auto t0 = Clock::now();
+      if (gpu) {
+        const auto res = hip_index->search_topk_dot_batch(query.vector_ptr_f32(q0), b, k);
+        gpu_kernel_ms += hip_index->last_kernel_ms();
+        lat.push_back(ms_between(t0, Clock::now()));
+        const size_t ke = res.size() / b;
+        for (uint32_t i = 0; i < b && ke; ++i) sink = sink + res[i * ke].score;
+      } else {
+        // bench-side batching: for each tile of rows, each row is scored against every query of the batch
+        std::vector<nvdb::TopKBuffer> best(b, nvdb::TopKBuffer(k));
+        const uint64_t N = base.count(), T = tile_vecs > 0 ? static_cast<uint64_t>(tile_vecs) : 1024;
+        const int64_t ntiles = static_cast<int64_t>((N + T - 1) / T);
+        if (mode == "omp") {
+#if defined(_OPENMP)
+          std::vector<std::vector<nvdb::TopKBuffer>> part(omp_get_max_threads(), std::vector<nvdb::TopKBuffer>(b, nvdb::TopKBuffer(k)));
+#pragma omp parallel for schedule(static)
+          for (int64_t t = 0; t < ntiles; ++t) {
+            auto& mine = part[omp_get_thread_num()];
+            for (uint64_t r = t * T; r < std::min<uint64_t>(N, (t + 1) * T); ++r)
+              for (uint32_t i = 0; i < b; ++i) mine[i].consider(r, nvdb::score_query_base_at(base, query.vector_ptr_f32(q0 + i), r, dim, dt));
+          }
+          for (auto& p : part) for (uint32_t i = 0; i < b; ++i) best[i].merge_from(p[i].raw());
+#endif
+        } else {
+          for (uint64_t r = 0; r < N; ++r)
+            for (uint32_t i = 0; i < b; ++i) best[i].consider(r, nvdb::score_query_base_at(base, query.vector_ptr_f32(q0 + i), r, dim, dt));
+        }
+        lat.push_back(ms_between(t0, Clock::now()));
+        for (uint32_t i = 0; i < b; ++i) { const auto r = best[i].finalize_sorted_desc(); if (!r.empty()) sink = sink + r[0].score; }
+      }
+    }
+  } else {
+    for (uint64_t qi = 0; qi < Q; ++qi) {
+      const auto t0 = Clock::now();
+      const auto topk = run_query(query.vector_ptr_f32(qi));
+      lat.push_back(ms_between(t0, Clock::now()));
+      if (gpu) gpu_kernel_ms += hip_index->last_kernel_ms();
+      if (!topk.empty()) sink = sink + topk[0].score;
+    }
+  }
+  const double total_ms = ms_between(t_all0, Clock::now());
+
+  std::sort(lat.begin(), lat.end());
+  auto pct = [&](double p) {
+    if (lat.empty()) return 0.0;
+    const double pos = p / 100.0 * static_cast<double>(lat.size() - 1);
+    const size_t i0 = static_cast<size_t>(std::floor(pos)), i1 = std::min(i0 + 1, lat.size() - 1);
+    return lat[i0] + (lat[i1] - lat[i0]) * (pos - static_cast<double>(i0));
+  };
+  if (batch_q > 1) std::cout << "batch_samples=" << lat.size() << "\n";
+  const double avg_query = total_ms / static_cast<double>(Q), qps = static_cast<double>(Q) * 1000.0 / total_ms;
+  std::cout << std::fixed << std::setprecision(3);
+  std::cout << "Total:     " << total_ms << " ms\n";
+  std::cout << "Avg_query: " << avg_query << " ms/query  (" << qps << " QPS)\n";
+  if (batch_q > 1) {
+    const int nb = static_cast<int>((Q + batch_q - 1) / batch_q);
+    std::cout << "Avg_batch: " << total_ms / nb << " ms/batch  (" << nb * 1000.0 / total_ms << " batches/s)\n";
+    std::cout << "batch_p50: " << pct(50) << " ms\n" << "batch_p95: " << pct(95) << " ms\n" << "batch_p99: " << pct(99) << " ms\n";
+  } else {
+    std::cout << "p50:       " << pct(50) << " ms\n" << "p95:       " << pct(95) << " ms\n" << "p99:       " << pct(99) << " ms\n";
+  }
+  std::cout << "sink=" << sink << "\n";
+  const double bytes_per_query = static_cast<double>(nvdb::bytes_for_payload_and_aux(base.count(), base.dim(), base.dtype()));
+  std::cout << std::setprecision(0) << "bytes_per_query=" << bytes_per_query << "\n" << std::setprecision(3);
+  std::cout << "payload_equiv_bandwidth_GBps=" << (avg_query > 0 ? bytes_per_query * 1e-6 / avg_query : 0.0) << "\n";
+  if (batch_q > 1) std::cout << "(note) payload_equiv_bandwidth_GBps may exceed DRAM peak due to cache reuse\n";
+  std::cout << "batch_q=" << batch_q << " tile_vecs=" << tile_vecs << " prefetch_dist=" << prefetch_dist << "\n";
+  if (gpu) {
+    const double passes = batch_q > 1 ? static_cast<double>((Q + batch_q - 1) / batch_q) : static_cast<double>(Q);
+    std::cout << "gpu_kernel_ms_total=" << gpu_kernel_ms << " gpu_passes=" << static_cast<uint64_t>(passes)
+              << " gpu_algorithmic_GBps=" << (gpu_kernel_ms > 0 ? passes * bytes_per_query * 1e-6 / gpu_kernel_ms : 0.0) << "\n";
+  }
+  return 0;
+}

@@ -1,0 +1,114 @@
+"""Host C++ layer (nano-vectordb_amd/host): the reference's nvdb:: surface re-implemented over the C ABI,
+and the CLI tools.  CPU tests pin the CPU modes against the reference goldens; GPU tests (marked) run the
+gpu modes and the refine harness."""
+import os
+import re
+import subprocess
+import struct
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from golden_inputs import CASES, make_case_inputs, sha
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "nano-vectordb_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(os.path.join(BIN, "nvdb_bench")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "nano-vectordb_amd"), "-j8"])
+    return BIN
+
+
+def run(tool, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([os.path.join(BIN, tool), *map(str, args)], check=True, capture_output=True, text=True, env=e).stdout
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory, built):
+    d = tmp_path_factory.mktemp("vecbin")
+    base32, queries = make_case_inputs("main768")
+    p = dict(b32=str(d / "b32.vecbin"), q=str(d / "q.raw12"), b16=str(d / "b16.vecbin"), b8=str(d / "b8.vecbin"), gt=str(d / "gt.gtbin"))
+    po.write_vecbin(p["b32"], base32, po.DT_F32)
+    po.write_raw12(p["q"], queries)
+    run("nvdb_convert_f16", p["b32"], p["b16"])
+    run("nvdb_quantize_i8", p["b32"], p["b8"])
+    return p
+
+
+def test_converter_tools_write_the_reference_bytes(files, golden):
+    b16 = po.read_vecbin(files["b16"])[0]
+    b8, _, sc = po.read_vecbin(files["b8"])
+    assert bytes(golden["main768_f16_sha"]).hex() == sha(b16)
+    assert bytes(golden["main768_i8_sha"]).hex() == sha(b8, sc)
+
+
+def test_nvdb_search_cpu_prints_the_reference_lines(files, golden):
+    assert run("nvdb_search", files["b32"], files["q"], 10) == bytes(golden["main768_search_stdout"]).decode()
+
+
+def test_nvdb_gt_build_cpu_modes_write_the_reference_gtbin(files, golden):
+    for mode in ("st", "omp"):
+        run("nvdb_gt_build", files["b16"], files["q"], 10, files["gt"], env={"GT_MODE": mode, "OMP_NUM_THREADS": "3"})
+        ids, meta = po.read_gtbin(files["gt"])
+        assert np.array_equal(ids, golden["main768_gtbin_f16_ids"])
+        assert np.fromfile(files["gt"], dtype=np.uint8)[:64].tobytes() == bytes(golden["main768_gtbin_raw"])
+
+
+@pytest.mark.parametrize("mode,extra", [("st", []), ("omp", ["2"]), ("omp", ["2", "1", "4", "512", "0"])])
+def test_nvdb_bench_cpu_output_lines(files, mode, extra):
+    out = run("nvdb_bench", files["b16"], files["q"], 10, mode, *extra, env={"OMP_NUM_THREADS": "2"})
+    lines = out.strip().splitlines()
+    assert lines[0].startswith(f"mode={mode} threads=")
+    assert lines[1] == "Base count=3000 dim=768 | Query count=8 | k=10 | warmup=" + (extra[1] if len(extra) > 1 else "5")
+    keys = [re.split(r"[=:]", l)[0] for l in lines[2:]]
+    if len(extra) > 2:   # batch_q = 4
+        assert keys == ["batch_samples", "Total", "Avg_query", "Avg_batch", "batch_p50", "batch_p95", "batch_p99", "sink",
+                        "bytes_per_query", "payload_equiv_bandwidth_GBps", "(note) payload_equiv_bandwidth_GBps may exceed DRAM peak due to cache reuse",
+                        "batch_q"]
+    else:
+        assert keys == ["Total", "Avg_query", "p50", "p95", "p99", "sink", "bytes_per_query", "payload_equiv_bandwidth_GBps", "batch_q"]
+    assert "bytes_per_query=4608000" in out                     # 3000 * 768 * 2
+    if po.Reference.available():                                # same sink (= sum of top-1 scores) as the real reference binary
+        ref = po.Reference().run_tool("nvdb_bench", files["b16"], files["q"], 10, mode, *extra, env={"OMP_NUM_THREADS": "2"})
+        assert re.search(r"sink=(\S+)", out).group(1) == re.search(r"sink=(\S+)", ref).group(1)
+        assert [re.split(r"[=:]", l)[0] for l in ref.strip().splitlines()[2:]] == keys
+
+
+def test_nvdb_bench_rejects_bad_input(files, built):
+    r = subprocess.run([os.path.join(BIN, "nvdb_bench")], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.startswith("Usage: nvdb_bench")
+    base32, _ = make_case_inputs("tiny")
+    p = os.path.join(os.path.dirname(files["q"]), "tiny.vecbin")
+    po.write_vecbin(p, base32, po.DT_F32)
+    r = subprocess.run([os.path.join(BIN, "nvdb_bench"), p, files["q"], "3"], capture_output=True, text=True)
+    assert r.returncode == 2 and "Dim mismatch" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_modes_of_the_tools(files, golden):
+    assert run("nvdb_search", files["b32"], files["q"], 10, "gpu") == bytes(golden["main768_search_stdout"]).decode()
+    run("nvdb_gt_build", files["b16"], files["q"], 10, files["gt"], env={"GT_MODE": "gpu"})
+    assert np.array_equal(po.read_gtbin(files["gt"])[0], golden["main768_gtbin_f16_ids"])
+    cpu = run("nvdb_bench", files["b16"], files["q"], 10, "st")
+    for extra in ([], ["0", "2", "4"]):
+        out = run("nvdb_bench", files["b16"], files["q"], 10, "gpu", *extra)
+        assert re.search(r"sink=(\S+)", out).group(1) == re.search(r"sink=(\S+)", cpu).group(1)
+        assert "gpu_kernel_ms_total=" in out.splitlines()[-1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtkey", ["b16", "b32"])
+def test_nvdb_cuda_refine_eval(files, dtkey):
+    out = run("nvdb_cuda_refine_eval", files[dtkey], files["q"], 10, env={"REFINE_K": "256"})
+    assert out.startswith("CUDA_REFINE=1 refine_ms_total=")
+    res = dict(kv.split("=") for kv in out.strip().splitlines()[-1].split()[1:])
+    assert res["refine_k"] == "256" and res["Q"] == "8" and res["k"] == "10" and res["refine_backend"] == "cuda"
+    assert float(res["recall_vs_cpu"]) == 1.0
+    assert "identical_rows=8/8" in out
