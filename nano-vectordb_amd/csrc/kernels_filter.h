@@ -114,7 +114,10 @@ __device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_
                : "=&s"(keep) : "v"(voff), "s"(lds_off), "s"(sbase) : "memory");
 }
 
-template <int DIM>
+// VAR selects timing-only ablation builds (results are wrong for VAR != 0; used by
+// nvdb_hip_debug_filter_variant): 1 = no direct-to-LDS loads in the loop, 2 = 1 + no barrier,
+// 3 = no MFMA (loads + LDS reads only), 4 = no epilogue compare, 5 = no LDS reads (MFMA on a constant).
+template <int DIM, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
     uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
@@ -223,8 +226,8 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
 
   for (uint32_t t = 0; t < NT; ++t) {
     // my pieces of tile t have landed once all but the newest stage's PPW loads are complete
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    __builtin_amdgcn_s_barrier();                  // everyone's pieces landed; buffer (t+2)%3 is free
+    if constexpr (VAR != 1 && VAR != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    if constexpr (VAR != 2) __builtin_amdgcn_s_barrier();   // everyone's pieces landed; buffer (t+2)%3 is free
 
     const char* next_tile = tile_ptr(t + 2);
     const uint32_t next_buf = (t + 2) % FILTER_STAGES;
@@ -233,16 +236,23 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
       return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256);
     };
     float4_t ar[RING];
+    if constexpr (VAR == 5) {
 #pragma unroll
-    for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(s);
+      for (int s = 0; s < RING; ++s) ar[s] = float4_t{1.f, 2.f, 3.f, 4.f};
+    }
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) if constexpr (VAR != 5) ar[s] = read_a(s);
     floatx16 acc0, acc1;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       // keep RING-1 fragment reads ahead of the MFMAs; the slot written here was consumed by step s-1
-      if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1);
+      if constexpr (VAR != 5) { if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1); }
       const float4_t a = ar[s % RING];
       const int f1 = KSTEPS + s;
-      if (s == 0) {
+      if constexpr (VAR == 3) {
+        asm volatile("" ::"v"(a));
+        if (s == 0) { acc0 = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; acc1 = acc0; }
+      } else if (s == 0) {
         NVDB_MFMA_F16_ZERO_A(acc0, a, bqa[0]);
         if (f1 < NFRAG_A) NVDB_MFMA_F16_ZERO_A(acc1, a, bqa[f1 < NFRAG_A ? f1 : 0]);
         else NVDB_MFMA_F16_ZERO_V(acc1, a, bqv[f1 >= NFRAG_A ? f1 - NFRAG_A : 0]);
@@ -252,15 +262,18 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
         else NVDB_MFMA_F16_ACC_V(acc1, a, bqv[f1 >= NFRAG_A ? f1 - NFRAG_A : 0]);
       }
       // stream tile t+2 in behind the MFMAs, one 1 KB piece every PIECE_EVERY k-steps
-      if (s % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_tile, next_buf, s / PIECE_EVERY);
+      if constexpr (VAR != 1 && VAR != 2) { if (s % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_tile, next_buf, s / PIECE_EVERY); }
     }
     // 32 wait states: MFMA result -> VALU read (the compiler does not see inside the asm)
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc0), "+v"(acc1));
 
     // ---- epilogue: threshold filter ------------------------------------------------------------
     bool any = false;
+    if constexpr (VAR == 4) { asm volatile("" ::"v"(acc0), "v"(acc1)); }
+    else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) any |= (acc0[r] >= thr_s[0]) | (acc1[r] >= thr_s[1]);
+      for (int r = 0; r < 16; ++r) any |= (acc0[r] >= thr_s[0]) | (acc1[r] >= thr_s[1]);
+    }
     if (__builtin_amdgcn_ballot_w64(any)) {
       const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
 #pragma unroll

@@ -613,6 +613,54 @@ nvdb_status nvdb_hip_collect_kernel_times(nvdb_hip_ctx* c, uint32_t* launches, d
   return NVDB_OK;
 }
 
+// Developer aid (not part of the drop-in surface): time ablation builds of the filter kernel on the
+// resident fp16 d=768 corpus with the query workspace left by the previous path-2 search.  Thresholds
+// are +inf (no survivors), so only the streaming/MFMA machinery is timed.
+nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* c, int variant, uint32_t nq, uint32_t reps, float* ms_per_launch) {
+  if (!c || !ms_per_launch) return NVDB_ERR_INVALID;
+  if (!c->rows || c->dtype != NVDB_DTYPE_F16 || c->dim != 768 || !c->q16.p) return fail(c, NVDB_ERR_UNSUPPORTED, "debug: run a path-2 search on an fp16 d=768 corpus first");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t QT = (nq + FILTER_QPB - 1) / FILTER_QPB, nq_pad = QT * FILTER_QPB;
+  DevBuf inf;
+  nvdb_status st = ensure(c, inf, nq_pad * 4);
+  if (st) return st;
+  fill_u32_kernel<<<(nq_pad + 255) / 256, 256, 0, c->stream>>>(static_cast<uint32_t*>(inf.p), 0x7F800000u, nq_pad);
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * 768 * 2;
+  const uint32_t n_al = static_cast<uint32_t>(c->n / FILTER_ROWS * FILTER_ROWS);
+  uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+#define NVDB_DBG_LAUNCH(V)                                                                                                     \
+  {                                                                                                                            \
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_f16_kernel<768, V>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+    for (uint32_t r = 0; r <= reps; ++r) {                                                                                     \
+      if (r == 1) HIPCHK(c, hipEventRecord(e0, c->stream));                                                                    \
+      filter_f16_kernel<768, V><<<nwg, 256, lds, c->stream>>>(static_cast<const _Float16*>(c->rows), 0, n_al, static_cast<const _Float16*>(c->q16.p), nq, QT, \
+          static_cast<const float*>(inf.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<Cand*>(c->cand.p),       \
+          static_cast<uint32_t*>(c->cnt.p), c->last_cap, static_cast<uint32_t*>(c->overflow.p));                               \
+    }                                                                                                                          \
+  }
+  switch (variant) {
+    case 0: NVDB_DBG_LAUNCH(0) break;
+    case 1: NVDB_DBG_LAUNCH(1) break;
+    case 2: NVDB_DBG_LAUNCH(2) break;
+    case 3: NVDB_DBG_LAUNCH(3) break;
+    case 4: NVDB_DBG_LAUNCH(4) break;
+    case 5: NVDB_DBG_LAUNCH(5) break;
+    default: return fail(c, NVDB_ERR_INVALID, "debug: unknown variant");
+  }
+#undef NVDB_DBG_LAUNCH
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_launch = ms / static_cast<float>(reps ? reps : 1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(inf.p);
+  return NVDB_OK;
+}
+
 nvdb_status nvdb_hip_get_stats(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   if (!c || !stats) return NVDB_ERR_INVALID;
   *stats = c->stats;
