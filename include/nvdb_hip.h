@@ -152,7 +152,7 @@ nvdb_status nvdb_hip_merge_topk_dev(nvdb_hip_ctx* ctx, const uint64_t* dev_ids, 
 nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint32_t nshards, uint32_t nq,
                                  uint32_t k, uint64_t* out_ids, float* out_scores);
 
-/* Tunables: "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "cand_cap", "min_filter_batch",
+/* Tunables: "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "chunk_growth", "cand_cap", "min_filter_batch",
  * "time_kernels" (1: bracket every launch of the dominant kernel with hipEvents on its stream).
  * Unknown key -> NVDB_ERR_INVALID. */
 nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* ctx, const char* key, int64_t value);

@@ -94,9 +94,10 @@ __device__ __forceinline__ float load1(const void* __restrict__ rowp, uint32_t i
 }
 
 // out[g] = reference score of (query g, this row).  q points at query 0 of the group, queries are
-// `dim` floats apart.  `scale` is the row's int8 scale (ignored otherwise).
-template <int DT, int QG, bool ALIGNED>
-__device__ __forceinline__ void exact_scores(const void* __restrict__ rowp, const float* __restrict__ q,
+// `qstride` floats apart (wave-uniform addresses: global memory -> scalar loads, LDS -> broadcast
+// ds_read_b128).  `scale` is the row's int8 scale (ignored otherwise).
+template <int DT, int QG, bool ALIGNED, typename QPtr>
+__device__ __forceinline__ void exact_scores(const void* __restrict__ rowp, QPtr q, uint32_t qstride,
                                              uint32_t dim, float scale, float (&out)[QG]) {
   float acc[QG][8];
 #pragma unroll
@@ -113,9 +114,15 @@ __device__ __forceinline__ void exact_scores(const void* __restrict__ rowp, cons
     float x[8];
     load8<DT, ALIGNED>(rowp, i, x);
 #pragma unroll
-    for (int g = 0; g < QG; ++g)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[g][j] = __builtin_fmaf(q[g * dim + i + j], x[j], acc[g][j]);
+    for (int g = 0; g < QG; ++g) {
+      // 8 consecutive query elements; 16-byte aligned whenever qstride % 4 == 0 (the staging pads it)
+      const float4 qa = *reinterpret_cast<const float4*>(&q[g * qstride + i]);
+      const float4 qb = *reinterpret_cast<const float4*>(&q[g * qstride + i + 4]);
+      acc[g][0] = __builtin_fmaf(qa.x, x[0], acc[g][0]); acc[g][1] = __builtin_fmaf(qa.y, x[1], acc[g][1]);
+      acc[g][2] = __builtin_fmaf(qa.z, x[2], acc[g][2]); acc[g][3] = __builtin_fmaf(qa.w, x[3], acc[g][3]);
+      acc[g][4] = __builtin_fmaf(qb.x, x[4], acc[g][4]); acc[g][5] = __builtin_fmaf(qb.y, x[5], acc[g][5]);
+      acc[g][6] = __builtin_fmaf(qb.z, x[6], acc[g][6]); acc[g][7] = __builtin_fmaf(qb.w, x[7], acc[g][7]);
+    }
   }
 #pragma unroll
   for (int g = 0; g < QG; ++g) out[g] = hsum8(acc[g]);
@@ -128,7 +135,7 @@ __device__ __forceinline__ void exact_scores(const void* __restrict__ rowp, cons
         for (int j = 0; j < 4; ++j) {
           const float x = load1<DT>(rowp, i + j);
 #pragma unroll
-          for (int g = 0; g < QG; ++g) { const float p = q[g * dim + i + j] * x; out[g] = out[g] + p; }
+          for (int g = 0; g < QG; ++g) { const float p = q[g * qstride + i + j] * x; out[g] = out[g] + p; }
         }
         i += 4;
       }
@@ -136,7 +143,7 @@ __device__ __forceinline__ void exact_scores(const void* __restrict__ rowp, cons
     for (; i < dim; ++i) {
       const float x = load1<DT>(rowp, i);
 #pragma unroll
-      for (int g = 0; g < QG; ++g) out[g] = __builtin_fmaf(q[g * dim + i], x, out[g]);
+      for (int g = 0; g < QG; ++g) out[g] = __builtin_fmaf(q[g * qstride + i], x, out[g]);
     }
   }
   if constexpr (DT == DT_I8) {
@@ -196,15 +203,21 @@ __device__ __forceinline__ void wtk_offer(WaveTopK& t, uint32_t k, bool pass, fl
 // exact streaming scan.  grid = (row splits P, ceil(nq/QG)); block = 256 (4 waves).
 // Each workgroup scans rows [lo,hi) of the chunk for QG queries and appends its <= k best
 // entries per query (those that also clear the query's global threshold) to the candidate lists.
+// The QG queries are staged once per workgroup in LDS (dynamic, QG * qstride floats, qstride = dim
+// rounded up to 4) and read back with broadcast ds_read_b128 -- scalar loads of 64 query elements
+// per step made the compiler spill SGPRs and spend ~150 SALU instructions per 64 FMAs.
 // ------------------------------------------------------------------------------------------------
 template <int DT, int QG, bool ALIGNED>
 __global__ __launch_bounds__(256) void scan_exact_kernel(
     const void* __restrict__ rows, const float* __restrict__ scales, uint32_t dim, uint32_t row_lo, uint32_t row_hi,
     const float* __restrict__ q32, uint32_t nq, uint32_t q_first, uint32_t k, const float* __restrict__ thr,
     Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t* __restrict__ overflow) {
-  __shared__ float lds_s[4][QG][64];
-  __shared__ uint32_t lds_id[4][QG][64];
-  __shared__ uint32_t lds_cnt[4][QG];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const uint32_t qstride = (dim + 3u) & ~3u;
+  float* q_lds = reinterpret_cast<float*>(smem_raw);                                   // [QG][qstride]
+  float (*lds_s)[QG][64] = reinterpret_cast<float (*)[QG][64]>(q_lds + QG * qstride);  // [4][QG][64]
+  uint32_t (*lds_id)[QG][64] = reinterpret_cast<uint32_t (*)[QG][64]>(reinterpret_cast<float*>(lds_s) + 4 * QG * 64);
+  uint32_t (*lds_cnt)[QG] = reinterpret_cast<uint32_t (*)[QG]>(reinterpret_cast<uint32_t*>(lds_id) + 4 * QG * 64);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t P = gridDim.x, p = blockIdx.x;
@@ -215,7 +228,12 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(
 
   // queries beyond nq: point at the last valid query and drop the result
   const uint32_t qbase = (qg0 + QG <= nq) ? qg0 : (nq >= static_cast<uint32_t>(QG) ? nq - QG : 0u);
-  const float* __restrict__ qptr = q32 + static_cast<uint64_t>(qbase) * dim;
+  for (uint32_t e = threadIdx.x; e < QG * qstride; e += 256) {
+    const uint32_t g = e / qstride, j = e % qstride;
+    q_lds[e] = (j < dim) ? q32[static_cast<uint64_t>(qbase + g) * dim + j] : 0.f;
+  }
+  __syncthreads();
+  const float* qptr = q_lds;
 
   WaveTopK tk[QG];
   float gthr[QG];
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(
     const uint32_t rrow = valid ? row : (hi - 1);
     float sc[QG];
     const float scale = (DT == DT_I8) ? scales[rrow] : 1.f;
-    exact_scores<DT, QG, ALIGNED>(row_ptr<DT>(rows, rrow, dim), qptr, dim, scale, sc);
+    exact_scores<DT, QG, ALIGNED>(row_ptr<DT>(rows, rrow, dim), qptr, qstride, dim, scale, sc);
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
       const bool pass = valid && sc[g] >= gthr[g] && wtk_accepts(tk[g], k, sc[g], row);
@@ -345,15 +363,20 @@ __global__ __launch_bounds__(256) void rescore_kernel(
   const uint32_t q = blockIdx.x;
   uint32_t m = cnt[q];
   if (m > cap) m = cap;
+  if (m == 0) return;
   if (threadIdx.x == 0 && total_cands) atomicAdd(total_cands, static_cast<unsigned long long>(m));
-  const float* __restrict__ qptr = q32 + static_cast<uint64_t>(q) * dim;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];      // the query, padded to a multiple of 4 floats
+  float* qptr = reinterpret_cast<float*>(smem_raw);
+  const uint32_t qstride = (dim + 3u) & ~3u;
+  for (uint32_t j = threadIdx.x; j < qstride; j += 256) qptr[j] = (j < dim) ? q32[static_cast<uint64_t>(q) * dim + j] : 0.f;
+  __syncthreads();
   const float eb = ebound ? ebound[q] : 0.f;
   Cand* mine = cand + static_cast<uint64_t>(q) * cap;
   for (uint32_t i = threadIdx.x; i < m; i += 256) {
     const Cand c = mine[i];
     float sc[1];
     const float scale = (DT == DT_I8) ? scales[c.row] : 1.f;
-    exact_scores<DT, 1, ALIGNED>(row_ptr<DT>(rows, c.row, dim), qptr, dim, scale, sc);
+    exact_scores<DT, 1, ALIGNED>(row_ptr<DT>(rows, c.row, dim), qptr, qstride, dim, scale, sc);
     if (ebound && !(__builtin_fabsf(sc[0] - c.score) <= eb)) atomicAdd(violations, 1u);
     mine[i].score = sc[0];
   }

@@ -32,8 +32,6 @@ typedef int int4_t __attribute__((ext_vector_type(4)));
 #define NVDB_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 constexpr int FILTER_ROWS = 32;          // corpus rows per tile (MFMA M)
-constexpr int FILTER_QPW = 64;           // queries per wave (2 MFMA N-blocks)
-constexpr int FILTER_QPB = 256;          // queries per workgroup
 constexpr int FILTER_STAGES = 3;
 
 // ------------------------------------------------------------------------------------------------
@@ -114,24 +112,32 @@ __device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_
                : "=&s"(keep) : "v"(voff), "s"(lds_off), "s"(sbase) : "memory");
 }
 
+// One survivor of the filter, logged by the wave that found it (16 bytes, one dwordx4 store).
+struct Hit { float score; uint32_t row; uint32_t qid; uint32_t pad; };
+constexpr uint32_t FILTER_LOGCAP = 256;            // entries per wave and launch
+
 // VAR selects timing-only ablation builds (results are wrong for VAR != 0; used by
 // nvdb_hip_debug_filter_variant): 1 = no direct-to-LDS loads in the loop, 2 = 1 + no barrier,
 // 3 = no MFMA (loads + LDS reads only), 4 = no epilogue compare, 5 = no LDS reads (MFMA on a constant).
-template <int DIM, int VAR = 0>
+// NB = 32-query blocks per wave: 2 -> 256 queries per workgroup (MFMA-bound batches), 1 -> 128 queries
+// per workgroup (half the MFMA work per streamed byte: the HBM-bound regime, nq <= 128).
+// RING = A fragments in flight LDS -> VGPR.
+template <int DIM, int NB, int VAR = 0, int RING = 6>
 __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
     uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
-    const float* __restrict__ qinv, Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap,
-    uint32_t* __restrict__ overflow) {
+    const float* __restrict__ qinv, Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt) {
   constexpr int KSTEPS = DIM / 16;                 // MFMA k-steps per tile
   constexpr int ROW_BYTES = DIM * 2;
   constexpr int STAGE_BYTES = FILTER_ROWS * ROW_BYTES;
   constexpr int PIECES = STAGE_BYTES / 1024;       // 1 KB direct-to-LDS pieces per stage
   constexpr int PPW = PIECES / 4;                  // pieces per wave
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
-  constexpr int NFRAG = 2 * KSTEPS;                // B fragments per wave (2 query blocks)
+  constexpr int NFRAG = NB * KSTEPS;               // B fragments per wave
   constexpr int NFRAG_A = NFRAG < 64 ? NFRAG : 64; // ... of which this many live in AGPRs
   constexpr int NFRAG_V = NFRAG - NFRAG_A;
+  constexpr int QPW = 32 * NB, QPB = 4 * QPW;      // queries per wave / per workgroup
+  static_assert(NB == 1 || NB == 2, "one or two 32-query blocks per wave");
   static_assert(DIM % 128 == 0, "swizzle assumes row stride is a multiple of 256 bytes");
   static_assert(PIECES % 4 == 0, "pieces must split evenly over 4 waves");
   static_assert(KSTEPS <= 64, "query block 0 must fit the AGPR-resident fragments");
@@ -140,6 +146,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r31 = lane & 31, hsel = lane >> 5;
+  const uint32_t wave_gid = blockIdx.x * 4 + wave;
 
   // ---- workgroup -> (row stream, query tile) ---------------------------------------------------
   const uint32_t nwg = gridDim.x, b = blockIdx.x;
@@ -154,13 +161,13 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
   const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
   const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
   const uint32_t NT = t_hi - t_lo;
-  if (NT == 0) return;
+  if (NT == 0) { if (lane == 0) hitcnt[wave_gid] = 0; return; }
 
-  // ---- stationary operand: this wave's 64 queries, all of K, in registers ----------------------
+  // ---- stationary operand: this wave's queries, all of K, in registers -------------------------
   // fragment f = nb*KSTEPS + s : query block nb (32 queries), k-step s.  Lane (r31,hsel) holds
   // q16[query r31 of the block][16 s + 8 hsel .. +8] -- the same k-slice the A fragment holds, so
   // the MFMA's internal k order is irrelevant.
-  const uint32_t qbase = qt * FILTER_QPB + wave * FILTER_QPW;
+  const uint32_t qbase = qt * QPB + wave * QPW;
   float4_t bqa[NFRAG_A];
   float4_t bqv[NFRAG_V > 0 ? NFRAG_V : 1];
 #pragma unroll
@@ -176,17 +183,18 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
   for (int f = 0; f < NFRAG_A; ++f) asm volatile("" ::"a"(bqa[f]));
 #pragma unroll
   for (int f = 0; f < NFRAG_V; ++f) asm volatile("" ::"v"(bqv[f]));
-  float thr_s[2], inv_s[2];
-  uint32_t qid[2];
+  float thr_s[NB], inv_s[NB];
+  uint32_t qid[NB];
+  bool wave_has_queries = false;
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
+  for (int nb = 0; nb < NB; ++nb) {
     qid[nb] = qbase + nb * 32 + r31;
     const bool real = qid[nb] < nq;
     thr_s[nb] = real ? thr[qid[nb]] * qscale[qid[nb]] : __builtin_huge_valf();
     inv_s[nb] = real ? qinv[qid[nb]] : 0.f;
+    asm volatile("" ::"v"(thr_s[nb]), "v"(inv_s[nb]));
   }
-
-  asm volatile("" ::"v"(thr_s[0]), "v"(thr_s[1]), "v"(inv_s[0]), "v"(inv_s[1]));
+  wave_has_queries = qbase < nq;                   // wave-uniform: padding-only waves skip their MFMAs
 
   // ---- per-lane source offsets of this wave's direct-to-LDS pieces -----------------------------
   // LDS image of a stage: [32 rows][CHUNKS_PER_ROW 16-byte chunks], chunk c of row r stored at
@@ -220,9 +228,10 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
 #pragma unroll
   for (int i = 0; i < PPW; ++i) issue_piece(tile_ptr(1), 1, i);
 
-  constexpr int RING = 4;                          // A fragments in flight LDS -> VGPR
   constexpr int PIECE_EVERY = KSTEPS / PPW;        // one direct-to-LDS piece per this many k-steps
   static_assert(KSTEPS % PPW == 0 && KSTEPS >= RING, "schedule assumes KSTEPS is a multiple of PPW");
+  uint32_t wcnt = 0;                               // survivors logged by this wave (uniform)
+  Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
 
   for (uint32_t t = 0; t < NT; ++t) {
     // my pieces of tile t have landed once all but the newest stage's PPW loads are complete
@@ -232,6 +241,11 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     const char* next_tile = tile_ptr(t + 2);
     const uint32_t next_buf = (t + 2) % FILTER_STAGES;
     const char* stage = smem + (t % FILTER_STAGES) * STAGE_BYTES;
+    if (!wave_has_queries) {                       // padding-only wave: keep streaming, skip the math
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) issue_piece(next_tile, next_buf, i);
+      continue;
+    }
     auto read_a = [&](int s) -> float4_t {
       return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256);
     };
@@ -242,56 +256,90 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     }
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) if constexpr (VAR != 5) ar[s] = read_a(s);
-    floatx16 acc0, acc1;
+    floatx16 acc[NB];
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       // keep RING-1 fragment reads ahead of the MFMAs; the slot written here was consumed by step s-1
       if constexpr (VAR != 5) { if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1); }
       const float4_t a = ar[s % RING];
-      const int f1 = KSTEPS + s;
       if constexpr (VAR == 3) {
         asm volatile("" ::"v"(a));
-        if (s == 0) { acc0 = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; acc1 = acc0; }
-      } else if (s == 0) {
-        NVDB_MFMA_F16_ZERO_A(acc0, a, bqa[0]);
-        if (f1 < NFRAG_A) NVDB_MFMA_F16_ZERO_A(acc1, a, bqa[f1 < NFRAG_A ? f1 : 0]);
-        else NVDB_MFMA_F16_ZERO_V(acc1, a, bqv[f1 >= NFRAG_A ? f1 - NFRAG_A : 0]);
+        if (s == 0) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        }
       } else {
-        NVDB_MFMA_F16_ACC_A(acc0, a, bqa[s]);
-        if (f1 < NFRAG_A) NVDB_MFMA_F16_ACC_A(acc1, a, bqa[f1 < NFRAG_A ? f1 : 0]);
-        else NVDB_MFMA_F16_ACC_V(acc1, a, bqv[f1 >= NFRAG_A ? f1 - NFRAG_A : 0]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int f = nb * KSTEPS + s;
+          if (s == 0) {
+            if (f < NFRAG_A) NVDB_MFMA_F16_ZERO_A(acc[nb], a, bqa[f < NFRAG_A ? f : 0]);
+            else NVDB_MFMA_F16_ZERO_V(acc[nb], a, bqv[f >= NFRAG_A ? f - NFRAG_A : 0]);
+          } else {
+            if (f < NFRAG_A) NVDB_MFMA_F16_ACC_A(acc[nb], a, bqa[f < NFRAG_A ? f : 0]);
+            else NVDB_MFMA_F16_ACC_V(acc[nb], a, bqv[f >= NFRAG_A ? f - NFRAG_A : 0]);
+          }
+        }
       }
       // stream tile t+2 in behind the MFMAs, one 1 KB piece every PIECE_EVERY k-steps
       if constexpr (VAR != 1 && VAR != 2) { if (s % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_tile, next_buf, s / PIECE_EVERY); }
     }
     // 32 wait states: MFMA result -> VALU read (the compiler does not see inside the asm)
-    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc0), "+v"(acc1));
+    if constexpr (NB == 2) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+    else asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]));
 
     // ---- epilogue: threshold filter ------------------------------------------------------------
     bool any = false;
-    if constexpr (VAR == 4) { asm volatile("" ::"v"(acc0), "v"(acc1)); }
-    else {
+    if constexpr (VAR == 4) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) any |= (acc0[r] >= thr_s[0]) | (acc1[r] >= thr_s[1]);
+      for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(acc[nb]));
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) any |= (acc[nb][r] >= thr_s[nb]);
     }
     if (__builtin_amdgcn_ballot_w64(any)) {
+      // rare path: log the survivors in this wave's own region (plain 16-byte stores, no atomics,
+      // nothing to wait for); scatter_hits_kernel files them under their queries afterwards.
       const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
+      for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = nb == 0 ? acc0[r] : acc1[r];
-          const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-          if (v >= thr_s[nb] && row < row_hi) {
-            const uint32_t slot = atomicAdd(&cnt[qid[nb]], 1u);
-            if (slot < cap) cand[static_cast<uint64_t>(qid[nb]) * cap + slot] = Cand{v * inv_s[nb], row};
-            else overflow[qid[nb]] = 1u;
+          const float v = acc[nb][r];
+          const bool hit = v >= thr_s[nb];
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+          if (m) {
+            const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+            if (hit && idx < FILTER_LOGCAP) {
+              const uint32_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+              mylog[idx] = Hit{v * inv_s[nb], row, qid[nb], 0u};
+            }
+            wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
           }
         }
       }
     }
   }
+  if (lane == 0) hitcnt[wave_gid] = wcnt;          // > FILTER_LOGCAP means entries were dropped
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two speculative stages before exit
+}
+
+// File every logged survivor under its query: cand[qid][slot] with slot from an atomic counter.
+// grid = number of wave logs, block = 64.
+__global__ __launch_bounds__(64) void scatter_hits_kernel(const Hit* __restrict__ hitlog, const uint32_t* __restrict__ hitcnt,
+                                                          Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap,
+                                                          uint32_t* __restrict__ overflow, uint32_t* __restrict__ log_overflow) {
+  const uint32_t w = blockIdx.x;
+  uint32_t n = hitcnt[w];
+  if (n > FILTER_LOGCAP) { if (threadIdx.x == 0) *log_overflow = 1u; n = FILTER_LOGCAP; }
+  for (uint32_t i = threadIdx.x; i < n; i += 64) {
+    const Hit h = hitlog[static_cast<uint64_t>(w) * FILTER_LOGCAP + i];
+    const uint32_t slot = atomicAdd(&cnt[h.qid], 1u);
+    if (slot < cap) cand[static_cast<uint64_t>(h.qid) * cap + slot] = Cand{h.score, h.row};
+    else overflow[h.qid] = 1u;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

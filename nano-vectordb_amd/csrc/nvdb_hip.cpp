@@ -56,12 +56,12 @@ struct nvdb_hip_ctx {
   float max_norm = 0.f;
 
   // grow-only workspace
-  DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc;
+  DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, hitcnt;
   DevBuf rq, rcand, rout_ids, rout_dist;           // refine
   void* pin = nullptr; size_t pin_bytes = 0;       // pinned staging
 
   // options
-  int64_t opt_path = 0, opt_chunk0 = 4096, opt_cap = 0, opt_min_filter_batch = 16;
+  int64_t opt_path = 0, opt_chunk0 = 4096, opt_cap = 0, opt_min_filter_batch = 16, opt_growth = 4;
 
   // state of the last search
   nvdb_hip_scan_stats stats{};
@@ -164,8 +164,10 @@ nvdb_status launch_scan_exact_qg(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
   uint32_t* cnt = static_cast<uint32_t*>(c->cnt.p);
   uint32_t* ovf = static_cast<uint32_t*>(c->overflow.p);
   const bool al = aligned_rows(c->dtype, c->dim);
+  const uint32_t qstride = (c->dim + 3u) & ~3u;
+  const size_t lds = static_cast<size_t>(QG) * qstride * 4 + static_cast<size_t>(4) * QG * 64 * 8 + 4 * QG * 4;
 #define NVDB_LAUNCH_SCAN(DT, AL) \
-  scan_exact_kernel<DT, QG, AL><<<grid, 256, 0, s>>>(c->rows, c->scales, c->dim, row_lo, row_hi, q32, nq, 0u, k, thr, cand, cnt, cap, ovf)
+  scan_exact_kernel<DT, QG, AL><<<grid, 256, lds, s>>>(c->rows, c->scales, c->dim, row_lo, row_hi, q32, nq, 0u, k, thr, cand, cnt, cap, ovf)
   if (c->dtype == NVDB_DTYPE_F32) { if (al) NVDB_LAUNCH_SCAN(DT_F32, true); else NVDB_LAUNCH_SCAN(DT_F32, false); }
   else if (c->dtype == NVDB_DTYPE_F16) { if (al) NVDB_LAUNCH_SCAN(DT_F16, true); else NVDB_LAUNCH_SCAN(DT_F16, false); }
   else { if (al) NVDB_LAUNCH_SCAN(DT_I8, true); else NVDB_LAUNCH_SCAN(DT_I8, false); }
@@ -177,7 +179,9 @@ nvdb_status launch_scan_exact_qg(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
 // rows [row_lo,row_hi) x all nq queries; appends at most P*k entries per query
 nvdb_status launch_scan_exact(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, const float* q32,
                               uint32_t nq, uint32_t k, const float* thr, uint32_t cap, uint32_t reserve) {
-  const uint32_t QG = nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1));
+  uint32_t QG = nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1));
+  while (QG > 1 && static_cast<size_t>(QG) * (((c->dim + 3u) & ~3u) * 4 + 4 * 64 * 8 + 16) > 60 * 1024) QG >>= 1;   // LDS budget
+  if (static_cast<size_t>((c->dim + 3u) & ~3u) * 4 + 4 * 64 * 8 + 16 > 60 * 1024) return fail(c, NVDB_ERR_UNSUPPORTED, "dim too large for the exact kernel's LDS query staging (max ~14800)");
   const uint32_t gy = (nq + QG - 1) / QG;
   const uint32_t rows = row_hi - row_lo;
   uint32_t pmax = (cap > reserve + k) ? (cap - reserve) / k : 1;       // list capacity
@@ -213,7 +217,8 @@ nvdb_status launch_rescore(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uin
   uint32_t* viol = static_cast<uint32_t*>(c->misc.p);
   unsigned long long* tot = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->misc.p) + 8);
   const bool al = aligned_rows(c->dtype, c->dim);
-#define NVDB_LAUNCH_RS(DT, AL) rescore_kernel<DT, AL><<<nq, 256, 0, s>>>(c->rows, c->scales, c->dim, q32, cand, cnt, cap, eb, viol, tot)
+  const size_t rs_lds = static_cast<size_t>((c->dim + 3u) & ~3u) * 4;
+#define NVDB_LAUNCH_RS(DT, AL) rescore_kernel<DT, AL><<<nq, 256, rs_lds, s>>>(c->rows, c->scales, c->dim, q32, cand, cnt, cap, eb, viol, tot)
   if (c->dtype == NVDB_DTYPE_F32) { if (al) NVDB_LAUNCH_RS(DT_F32, true); else NVDB_LAUNCH_RS(DT_F32, false); }
   else if (c->dtype == NVDB_DTYPE_F16) { if (al) NVDB_LAUNCH_RS(DT_F16, true); else NVDB_LAUNCH_RS(DT_F16, false); }
   else { if (al) NVDB_LAUNCH_RS(DT_I8, true); else NVDB_LAUNCH_RS(DT_I8, false); }
@@ -226,29 +231,39 @@ bool filter_supported(const nvdb_hip_ctx* c) {
   return c->dtype == NVDB_DTYPE_F16 && (c->dim == 768 || c->dim == 384);
 }
 
-template <int DIM>
+template <int DIM, int NB>
 nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
                               uint32_t cap) {
   constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * DIM * 2;
-  const void* fn = reinterpret_cast<const void*>(filter_f16_kernel<DIM>);
+  const void* fn = reinterpret_cast<const void*>(filter_f16_kernel<DIM, NB>);
   if (!c->lds_attr_set.count(fn)) {
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     c->lds_attr_set.insert(fn);
   }
   uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
   if (nwg == 0) nwg = QT;
-  filter_f16_kernel<DIM><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), row_lo, row_hi,
-                                               static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
-                                               static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
-                                               static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap,
-                                               static_cast<uint32_t*>(c->overflow.p));
+  nvdb_status st;
+  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+  if ((st = ensure(c, c->hitcnt, static_cast<size_t>(nwg) * 4 * 4))) return st;
+  filter_f16_kernel<DIM, NB><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), row_lo, row_hi,
+                                                   static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
+                                                   static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
+                                                   static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p));
+  HIPCHK(c, hipGetLastError());
+  scatter_hits_kernel<<<nwg * 4, 64, 0, s>>>(static_cast<const Hit*>(c->hitlog.p), static_cast<const uint32_t*>(c->hitcnt.p),
+                                             static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap,
+                                             static_cast<uint32_t*>(c->overflow.p), static_cast<uint32_t*>(c->misc.p) + 1);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
 
+// NB = 32-query blocks per wave: 1 for nq <= 128 (HBM-bound regime), else 2
+uint32_t filter_nb(uint32_t nq) { return nq <= 128 ? 1u : 2u; }
+
 nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT, uint32_t cap) {
-  if (c->dim == 768) return launch_filter_dim<768>(c, s, row_lo, row_hi, nq, QT, cap);
-  if (c->dim == 384) return launch_filter_dim<384>(c, s, row_lo, row_hi, nq, QT, cap);
+  const uint32_t nb = filter_nb(nq);
+  if (c->dim == 768) return nb == 1 ? launch_filter_dim<768, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<768, 2>(c, s, row_lo, row_hi, nq, QT, cap);
+  if (c->dim == 384) return nb == 1 ? launch_filter_dim<384, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<384, 2>(c, s, row_lo, row_hi, nq, QT, cap);
   return fail(c, NVDB_ERR_UNSUPPORTED, "filter kernel: unsupported dim");
 }
 
@@ -269,8 +284,9 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   uint32_t cap = c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : (nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
   if (cap < 4 * k_eff) cap = std::min<uint32_t>(SELECT_MAX_CAP, 4 * k_eff);
-  const uint32_t QT = (nq + FILTER_QPB - 1) / FILTER_QPB;
-  const uint32_t nq_pad = QT * FILTER_QPB;
+  const uint32_t QPB = 128u * filter_nb(nq);                 // queries per filter workgroup
+  const uint32_t QT = (nq + QPB - 1) / QPB;
+  const uint32_t nq_pad = QT * QPB;
 
   nvdb_status st;
   if ((st = ensure(c, c->thr, nq_pad * 4))) return st;
@@ -331,7 +347,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     c->stats.chunks++;
     c->stats.rows_scanned += static_cast<uint64_t>(hi - r) * QT;
     r = hi;
-    size *= 2;
+    size = static_cast<uint64_t>(r) * (static_cast<uint64_t>(c->opt_growth) - 1);   // rows seen so far x (growth-1)
   }
   if (n_al < n) {   // ragged tail: exact scores, pruned by the current thresholds
     if ((st = launch_scan_exact(c, s, n_al, n, dev_q, nq, k_eff, static_cast<const float*>(c->thr.p), cap, 0))) return st;
@@ -384,7 +400,7 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   free_corpus(c);
   for (DevBuf* b : {&c->q32, &c->q16, &c->qscale, &c->qinv, &c->ebound, &c->slack, &c->thr, &c->cnt, &c->overflow, &c->cand,
-                    &c->out_ids, &c->out_scores, &c->misc, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
+                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->hitcnt, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
     if (b->p) (void)hipFree(b->p);
   if (c->pin) (void)hipHostFree(c->pin);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -486,6 +502,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "chunk0_rows") { if (value < 256) return fail(c, NVDB_ERR_INVALID, "chunk0_rows must be >= 256"); c->opt_chunk0 = value; }
   else if (k == "cand_cap") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "cand_cap out of range"); c->opt_cap = value; }
   else if (k == "time_kernels") { c->opt_time_kernels = value ? 1 : 0; }
+  else if (k == "chunk_growth") { if (value < 2 || value > 64) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be in [2,64]"); c->opt_growth = value; }
   else if (k == "min_filter_batch") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "min_filter_batch must be >= 1"); c->opt_min_filter_batch = value; }
   else return fail(c, NVDB_ERR_INVALID, "unknown option: " + k);
   return NVDB_OK;
@@ -520,6 +537,7 @@ nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   if (c->misc.p) HIPCHK(c, hipMemcpy(misc, c->misc.p, 16, hipMemcpyDeviceToHost));
   uint32_t nov = 0;
   for (uint32_t v : ovf) nov += v ? 1u : 0u;
+  if (misc[1]) nov = c->last_nq;                 // a wave's survivor log overflowed: which queries lost entries is unknown
   c->stats.overflow_queries = nov;
   c->stats.bound_violations = misc[0];
   unsigned long long tot; std::memcpy(&tot, &misc[2], 8);
@@ -620,7 +638,8 @@ nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* c, int variant, uint32_t
   if (!c || !ms_per_launch) return NVDB_ERR_INVALID;
   if (!c->rows || c->dtype != NVDB_DTYPE_F16 || c->dim != 768 || !c->q16.p) return fail(c, NVDB_ERR_UNSUPPORTED, "debug: run a path-2 search on an fp16 d=768 corpus first");
   HIPCHK(c, hipSetDevice(c->device));
-  const uint32_t QT = (nq + FILTER_QPB - 1) / FILTER_QPB, nq_pad = QT * FILTER_QPB;
+  if (nq <= 128) return fail(c, NVDB_ERR_UNSUPPORTED, "debug: variants are built for nq > 128 (NB = 2)");
+  const uint32_t QT = (nq + 255) / 256, nq_pad = QT * 256;
   DevBuf inf;
   nvdb_status st = ensure(c, inf, nq_pad * 4);
   if (st) return st;
@@ -630,23 +649,27 @@ nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* c, int variant, uint32_t
   uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
-#define NVDB_DBG_LAUNCH(V)                                                                                                     \
+#define NVDB_DBG_LAUNCH(V, RG)                                                                                                 \
   {                                                                                                                            \
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_f16_kernel<768, V>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_f16_kernel<768, 2, V, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
     for (uint32_t r = 0; r <= reps; ++r) {                                                                                     \
       if (r == 1) HIPCHK(c, hipEventRecord(e0, c->stream));                                                                    \
-      filter_f16_kernel<768, V><<<nwg, 256, lds, c->stream>>>(static_cast<const _Float16*>(c->rows), 0, n_al, static_cast<const _Float16*>(c->q16.p), nq, QT, \
-          static_cast<const float*>(inf.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<Cand*>(c->cand.p),       \
-          static_cast<uint32_t*>(c->cnt.p), c->last_cap, static_cast<uint32_t*>(c->overflow.p));                               \
+      filter_f16_kernel<768, 2, V, RG><<<nwg, 256, lds, c->stream>>>(static_cast<const _Float16*>(c->rows), 0, n_al, static_cast<const _Float16*>(c->q16.p), nq, QT, \
+          static_cast<const float*>(inf.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),     \
+          static_cast<uint32_t*>(c->hitcnt.p));                                                                                \
     }                                                                                                                          \
   }
   switch (variant) {
-    case 0: NVDB_DBG_LAUNCH(0) break;
-    case 1: NVDB_DBG_LAUNCH(1) break;
-    case 2: NVDB_DBG_LAUNCH(2) break;
-    case 3: NVDB_DBG_LAUNCH(3) break;
-    case 4: NVDB_DBG_LAUNCH(4) break;
-    case 5: NVDB_DBG_LAUNCH(5) break;
+    case 0: NVDB_DBG_LAUNCH(0, 4) break;
+    case 1: NVDB_DBG_LAUNCH(1, 4) break;
+    case 2: NVDB_DBG_LAUNCH(2, 4) break;
+    case 3: NVDB_DBG_LAUNCH(3, 4) break;
+    case 4: NVDB_DBG_LAUNCH(4, 4) break;
+    case 5: NVDB_DBG_LAUNCH(5, 4) break;
+    case 6: NVDB_DBG_LAUNCH(0, 6) break;
+    case 7: NVDB_DBG_LAUNCH(0, 8) break;
+    case 8: NVDB_DBG_LAUNCH(0, 3) break;
+    case 9: NVDB_DBG_LAUNCH(0, 12) break;
     default: return fail(c, NVDB_ERR_INVALID, "debug: unknown variant");
   }
 #undef NVDB_DBG_LAUNCH
