@@ -664,7 +664,6 @@ nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* c, int variant, uint32_t
     case 1: NVDB_DBG_LAUNCH(1, 4) break;
     case 2: NVDB_DBG_LAUNCH(2, 4) break;
     case 3: NVDB_DBG_LAUNCH(3, 4) break;
-    case 4: NVDB_DBG_LAUNCH(4, 4) break;
     case 5: NVDB_DBG_LAUNCH(5, 4) break;
     case 6: NVDB_DBG_LAUNCH(0, 6) break;
     case 7: NVDB_DBG_LAUNCH(0, 8) break;
