@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--dtype", default="f16", choices=["f16"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "i8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=96)
@@ -78,14 +78,14 @@ def cpu_baseline(ctx, args, nvdb_amd):
     import pyoracle as po
     cores = host_cpu_share()
     n_s, nq_s = min(args.cpu_sample_rows, args.rows), args.cpu_sample_queries
-    rows, _ = ctx.download_rows(0, n_s)                       # same synthetic rows the GPU scans
+    rows, rsc = ctx.download_rows(0, n_s)                     # same synthetic rows the GPU scans
     queries = nvdb_amd.synth_rows_f32(SEED + 1, 0, nq_s, args.dim)
     scale = n_s / float(args.rows)
     if po.Reference.available():
         ref = po.Reference()
         tmp = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"nvdb_bench_{os.getpid()}.vecbin")
         try:
-            po.write_vecbin(tmp, rows, po.DT_F16)
+            po.write_vecbin(tmp, rows, po.DT_F16 if args.dtype == "f16" else po.DT_I8, rsc)
             h = ref.open(tmp)
             ref.flat_search(h, queries[:4], args.k, mode=1, threads=cores, want_results=False)        # warm-up
             _, _, ms = ref.flat_search(h, queries, args.k, mode=1, threads=cores, want_results=False)
@@ -98,13 +98,13 @@ def cpu_baseline(ctx, args, nvdb_amd):
         orc = po.Oracle()
         t0 = time.time()
         for q in queries:
-            orc.flat_topk_omp(rows, po.DT_F16, q, args.k, cores)
+            orc.flat_topk_omp(rows, po.DT_F16 if args.dtype == "f16" else po.DT_I8, q, args.k, cores, rsc)
         ms = (time.time() - t0) * 1e3
         kind = "port"
     qps_sample = nq_s / (ms * 1e-3)
     return {"value": qps_sample * scale, "unit": "queries/s", "cores": cores, "kind": kind,
             "sample": f"{nq_s} queries, one at a time (FlatIndexOMP, {cores} OpenMP threads) over the first {n_s} rows of the same "
-                      f"fp16 corpus: {qps_sample:.2f} queries/s measured ({n_s * args.dim * 2 * qps_sample / 1e9:.1f} GB/s), "
+                      f"{args.dtype} corpus: {qps_sample:.2f} queries/s measured ({n_s * args.dim * (2 if args.dtype == 'f16' else 1) * qps_sample / 1e9:.1f} GB/s), "
                       f"scaled by {n_s}/{args.rows} rows"}
 
 
@@ -126,7 +126,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    dt = nvdb_amd.DT_F16
+    dt = nvdb_amd.DT_F16 if args.dtype == "f16" else nvdb_amd.DT_I8
+    bpr = args.dim * 2 if args.dtype == "f16" else args.dim + 4      # algorithmic bytes per corpus row
     N, B, D, K = args.rows, args.batch, args.dim, args.k
     from nvdb_amd.sharding import shard_range
     lo, hi = shard_range(N, rank, world)
@@ -183,8 +184,11 @@ def main():
         ok = np.array_equal(fi, ei) and np.array_equal(fs.view(np.uint32), es.view(np.uint32))
         for qi in range(4):
             for j in range(K):
-                row, _ = ctx.download_rows(int(fi[qi, j]) - lo, 1)
-                s = orc.lib.oracle_dot_f32_f16base(po._p(qhost[qi], po._f32p), row.ctypes.data, D)
+                row, rsc = ctx.download_rows(int(fi[qi, j]) - lo, 1)
+                if args.dtype == "f16":
+                    s = orc.lib.oracle_dot_f32_f16base(po._p(qhost[qi], po._f32p), row.ctypes.data, D)
+                else:
+                    s = orc.lib.oracle_dot_f32_i8base(po._p(qhost[qi], po._f32p), row.ctypes.data, D, float(rsc[0]))
                 ok = ok and np.float32(s).view(np.uint32) == fs[qi, j].view(np.uint32)
         parity = "ok" if ok else "FAILED"
         if not ok:
@@ -213,11 +217,11 @@ def main():
         "metric": "QPS + effective HBM GB/s, flat-scan top-10 d=768",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"fp16 flat-scan top-{K}, N={N} d={D}, batch={B}", "rows_total": N,
+        "dtype": "f16" if args.dtype == "f16" else "i8", "data": "synthetic",
+        "config": {"workload": f"{'fp16' if args.dtype == 'f16' else 'int8+scale'} flat-scan top-{K}, N={N} d={D}, batch={B}", "rows_total": N,
                    "rows_per_gpu": hi - lo, "batch": B, "k": K, "dim": D,
                    "parallelism": "1 GPU" if world == 1 else f"corpus row-sharded x{world}, RCCL all-gather of per-shard top-k"},
-        "effective_hbm_GBps": (N * D * 2 / 1e9) / (ms_per_step * 1e-3),        # corpus bytes / pass time, all GPUs
+        "effective_hbm_GBps": (N * bpr / 1e9) / (ms_per_step * 1e-3),          # corpus bytes / pass time, all GPUs
         "parity": parity,
         "scan": {"path": stats["path"], "chunks": stats["chunks"], "candidates_per_query": stats["candidates"] / max(B, 1),
                  "bound_violations": stats["bound_violations"], "overflow_queries": stats["overflow_queries"]},
@@ -225,8 +229,10 @@ def main():
     if kt["launches"]:
         sec = kt["ms"] * 1e-3
         ach = kt["flops"] / sec / 1e12
-        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS,
-                           "traffic": None, "kernel": "filter_f16_kernel<768>", "launches": kt["launches"],
+        peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_I8_TOPS
+        # the int8 kernel issues TWO integer MFMAs per query block (hi/lo planes): algorithmic ops stay 2*B*N*d
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if args.dtype == "f16" else "TOP/s", "frac": ach / peak,
+                           "traffic": None, "kernel": "filter_f16_kernel<768>" if args.dtype == "f16" else "filter_i8_kernel<768>", "launches": kt["launches"],
                            "avg_launch_ms": kt["ms"] / kt["launches"], "kernel_time_share": kt["ms"] / (elapsed * 1e3),
                            "hbm_GBps_algorithmic": kt["bytes"] / sec / 1e9, "hbm_frac": kt["bytes"] / sec / 1e9 / PEAK_HBM_GBPS}
     else:
@@ -251,7 +257,7 @@ def main():
             k2 = ctx.collect_kernel_times()
             s2 = ctx.search_check()
             sweep.append({"batch": b, "qps": reps * b / el, "ms_per_pass": el * 1e3 / reps, "path": s2["path"],
-                          "hbm_GBps": N * D * 2 / 1e9 / (el / reps), "hbm_frac": N * D * 2 / 1e9 / (el / reps) / PEAK_HBM_GBPS,
+                          "hbm_GBps": N * bpr / 1e9 / (el / reps), "hbm_frac": N * bpr / 1e9 / (el / reps) / PEAK_HBM_GBPS,
                           "tflops": 2.0 * b * N * D / (el / reps) / 1e12,
                           "filter_kernel_ms_per_pass": (k2["ms"] / reps) if k2["launches"] else None})
         out["sweep"] = sweep

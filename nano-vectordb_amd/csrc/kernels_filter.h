@@ -342,6 +342,204 @@ __global__ __launch_bounds__(64) void scatter_hits_kernel(const Hit* __restrict_
   }
 }
 
+// ================================================================================================
+// int8(+scale) corpus: the same streaming structure on the integer matrix cores.
+//
+// The reference dequantises on the fly and keeps the query in fp32 (src/simd_dot.cpp:160-199).  Here the
+// filter quantises the QUERY to 15 bits as two int8 planes, q_i ~ s_q * (128*hi_i + lo_i) with
+// hi in [-127,127], lo in [-64,63], and runs two v_mfma_i32_32x32x32_i8 per A fragment (hi plane, lo
+// plane); integer accumulation is exact, so the only filter error is the query quantisation:
+//   |filter - cpu_score| <= (sqrt(dim) * s_q / 2) * max_row(||x_int8|| * scale)  (+ fp32 rounding),
+// which prep_q8_kernel turns into ebound/slack exactly like the fp16 path.  One wave = 32 queries
+// (two planes x 24 k-steps = 48 fragments = 192 AGPRs), one workgroup = 128 queries.
+// Per stage: 32 rows x DIM bytes of corpus + the tile's 32 row scales (one extra 1 KB piece per wave,
+// into the wave's own LDS slot, so that no ordinary global load -- whose compiler-inserted vmcnt wait
+// would drain the stream -- is needed in the loop).
+// ================================================================================================
+__global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim,
+                                                      float max_row_norm, signed char* __restrict__ qhi,
+                                                      signed char* __restrict__ qlo, float* __restrict__ qscale,
+                                                      float* __restrict__ qinv, float* __restrict__ ebound,
+                                                      float* __restrict__ slack) {
+  __shared__ float red_max[4], red_ss[4];
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  if (q >= nq) {
+    for (uint32_t i = tid; i < dim; i += 256) { qhi[static_cast<uint64_t>(q) * dim + i] = 0; qlo[static_cast<uint64_t>(q) * dim + i] = 0; }
+    if (tid == 0) { qscale[q] = 1.f; qinv[q] = 1.f; ebound[q] = 0.f; slack[q] = 0.f; }
+    return;
+  }
+  const float* src = q32 + static_cast<uint64_t>(q) * dim;
+  float mx = 0.f, ss = 0.f;
+  for (uint32_t i = tid; i < dim; i += 256) { const float v = src[i]; mx = fmaxf(mx, fabsf(v)); ss = __builtin_fmaf(v, v, ss); }
+  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); ss += __shfl_xor(ss, o); }
+  if ((tid & 63) == 0) { red_max[tid >> 6] = mx; red_ss[tid >> 6] = ss; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
+  ss = (red_ss[0] + red_ss[1]) + (red_ss[2] + red_ss[3]);
+  const float sq = (mx > 0.f && mx < 3.0e38f) ? mx / 16256.f : 1.f;
+  const float isq = 1.0f / sq;
+  for (uint32_t i = tid; i < dim; i += 256) {
+    int t = static_cast<int>(rintf(src[i] * isq));
+    t = t > 16256 ? 16256 : (t < -16256 ? -16256 : t);
+    const int hi = (t + 64) >> 7;                 // floor((t+64)/128), arithmetic shift
+    const int lo = t - (hi << 7);                 // in [-64, 63]
+    qhi[static_cast<uint64_t>(q) * dim + i] = static_cast<signed char>(hi);
+    qlo[static_cast<uint64_t>(q) * dim + i] = static_cast<signed char>(lo);
+  }
+  if (tid == 0) {
+    const float nrm = sqrtf(ss) * 1.0001f;
+    // quantisation: |dq_i| <= 0.5 s_q (+ the rounding of q*isq: <= 2^-23 |q_i|); fp32 chains: 1e-5 ||q||
+    const float eb = (0.5005f * sqrtf(static_cast<float>(dim)) * sq + 1.0e-5f * nrm) * max_row_norm * 1.001f + 1e-30f;
+    qscale[q] = isq; qinv[q] = sq; ebound[q] = eb; slack[q] = 2.f * eb;
+  }
+}
+
+#define NVDB_MFMA_I8_ZERO(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b))
+#define NVDB_MFMA_I8_ACC(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
+
+template <int DIM, int RING = 6>
+__global__ __launch_bounds__(256, 1) void filter_i8_kernel(
+    const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
+    const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
+    const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qinv,
+    Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt) {
+  constexpr int KSTEPS = DIM / 32;                 // v_mfma_i32_32x32x32_i8: K = 32
+  constexpr int ROW_BYTES = DIM;
+  constexpr int DATA_BYTES = FILTER_ROWS * ROW_BYTES;
+  constexpr int STAGE_BYTES = DATA_BYTES + 4 * 1024;   // + one 1 KB scales slot per wave
+  constexpr int PIECES = DATA_BYTES / 1024;
+  constexpr int PPW = PIECES / 4;                  // corpus pieces per wave
+  constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
+  static_assert(DIM % 256 == 0, "swizzle assumes the int8 row stride is a multiple of 256 bytes");
+  static_assert(PIECES % 4 == 0 && KSTEPS % PPW == 0 && 2 * KSTEPS <= 64, "shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, hsel = lane >> 5;
+  const uint32_t wave_gid = blockIdx.x * 4 + wave;
+
+  const uint32_t nwg = gridDim.x, b = blockIdx.x;
+  const uint32_t S = nwg / QT;
+  uint32_t stream, qt;
+  if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
+  else { qt = b % QT; stream = b / QT; }
+  const uint32_t tiles_total = (row_hi - row_lo) / FILTER_ROWS;
+  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
+  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const uint32_t NT = t_hi - t_lo;
+  if (NT == 0) { if (lane == 0) hitcnt[wave_gid] = 0; return; }
+
+  // stationary operand: 32 queries x two int8 planes x all of K, in AGPRs.  Lane (r31,hsel) holds bytes
+  // [32 s + 16 hsel, +16) of its query -- the same k-slice the A fragment holds.
+  const uint32_t qbase = qt * 128u + wave * 32u;
+  float4_t bq[2 * KSTEPS];
+#pragma unroll
+  for (int f = 0; f < 2 * KSTEPS; ++f) {
+    const signed char* plane = (f < KSTEPS) ? qhi : qlo;
+    const int s = f % KSTEPS;
+    bq[f] = *reinterpret_cast<const float4_t*>(plane + static_cast<uint64_t>(qbase + r31) * DIM + 32 * s + 16 * hsel);
+  }
+#pragma unroll
+  for (int f = 0; f < 2 * KSTEPS; ++f) asm volatile("" ::"a"(bq[f]));
+  const uint32_t qid = qbase + r31;
+  const bool real = qid < nq;
+  float thr_s = real ? thr[qid] * qscale[qid] : __builtin_huge_valf();   // threshold in units of s_q
+  float inv_s = real ? qinv[qid] : 0.f;
+  asm volatile("" ::"v"(thr_s), "v"(inv_s));
+  const bool wave_has_queries = qbase < nq;
+
+  uint32_t src_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const uint32_t P = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
+    const uint32_t r = P / CHUNKS_PER_ROW, cpos = P % CHUNKS_PER_ROW;
+    src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
+  }
+  const uint32_t sc_off = (lane & 7) * 16;         // 32 row scales = 128 bytes; lanes >= 8 re-load the same chunks
+  const uint32_t a_base = r31 * ROW_BYTES + ((static_cast<uint32_t>(hsel) ^ (r31 & 15u)) << 4);
+
+  const char* gbase = reinterpret_cast<const char*>(rows);
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
+  auto tile_row0 = [&](uint32_t t_rel) -> uint32_t { return row_lo + (t_lo + (t_rel < NT ? t_rel : NT - 1)) * FILTER_ROWS; };
+  auto issue_piece = [&](uint32_t row0, uint32_t buf, int i) {
+    glds16(src_off[i], gbase + static_cast<uint64_t>(row0) * ROW_BYTES, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
+  };
+  auto issue_scales = [&](uint32_t row0, uint32_t buf) {
+    glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 1024);
+  };
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(tile_row0(st), st, i);
+    issue_scales(tile_row0(st), st);
+  }
+
+  constexpr int PIECE_EVERY = KSTEPS / PPW;
+  uint32_t wcnt = 0;
+  Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
+
+  for (uint32_t t = 0; t < NT; ++t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const uint32_t next_row0 = tile_row0(t + 2), next_buf = (t + 2) % FILTER_STAGES;
+    const char* stage = smem + (t % FILTER_STAGES) * STAGE_BYTES;
+    if (!wave_has_queries) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) issue_piece(next_row0, next_buf, i);
+      issue_scales(next_row0, next_buf);
+      continue;
+    }
+    auto read_a = [&](int s) -> float4_t {
+      return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256);
+    };
+    float4_t ar[RING];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(s);
+    intx16 acc_hi, acc_lo;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1);
+      const float4_t a = ar[s % RING];
+      if (s == 0) { NVDB_MFMA_I8_ZERO(acc_hi, a, bq[0]); NVDB_MFMA_I8_ZERO(acc_lo, a, bq[KSTEPS]); }
+      else { NVDB_MFMA_I8_ACC(acc_hi, a, bq[s]); NVDB_MFMA_I8_ACC(acc_lo, a, bq[KSTEPS + s]); }
+      if (s % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_row0, next_buf, s / PIECE_EVERY);
+      if (s == 1) issue_scales(next_row0, next_buf);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc_hi), "+v"(acc_lo));
+
+    // epilogue: f = (128*H + L) * scale_row  compared with thr/s_q ; rows (r&3) + 8*(r>>2) + 4*hsel
+    const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 1024);
+    float fv[16];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 sc4 = *reinterpret_cast<const float4*>(sc_lds + 8 * j + 4 * hsel);
+      const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * j + i;
+        fv[r] = __builtin_fmaf(static_cast<float>(acc_hi[r]), 128.f, static_cast<float>(acc_lo[r])) * scv[i];
+        any |= fv[r] >= thr_s;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(any)) {
+      const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool hit = fv[r] >= thr_s;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (m) {
+          const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+          if (hit && idx < FILTER_LOGCAP) mylog[idx] = Hit{fv[r] * inv_s, row0 + (r & 3) + 8 * (r >> 2) + 4 * hsel, qid, 0u};
+          wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
+        }
+      }
+    }
+  }
+  if (lane == 0) hitcnt[wave_gid] = wcnt;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------------
 // synthetic corpus generator: one wave per row (bit-identical to nvdb_synth_rows_f32 on the host
 // followed by the RNE half conversion / the reference's int8 quantiser).

@@ -61,7 +61,7 @@ struct nvdb_hip_ctx {
   void* pin = nullptr; size_t pin_bytes = 0;       // pinned staging
 
   // options
-  int64_t opt_path = 0, opt_chunk0 = 4096, opt_cap = 0, opt_min_filter_batch = 16, opt_growth = 4;
+  int64_t opt_path = 0, opt_chunk0 = 4096, opt_cap = 0, opt_min_filter_batch = 1, opt_growth = 4;
 
   // state of the last search
   nvdb_hip_scan_stats stats{};
@@ -228,7 +228,9 @@ nvdb_status launch_rescore(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uin
 }
 
 bool filter_supported(const nvdb_hip_ctx* c) {
-  return c->dtype == NVDB_DTYPE_F16 && (c->dim == 768 || c->dim == 384);
+  if (c->dtype == NVDB_DTYPE_F16) return c->dim == 768 || c->dim == 384;
+  if (c->dtype == NVDB_DTYPE_I8) return c->dim == 768 || c->dim == 512 || c->dim == 256;   // int8 rows: stride % 256 == 0
+  return false;
 }
 
 template <int DIM, int NB>
@@ -257,11 +259,46 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
   return NVDB_OK;
 }
 
-// NB = 32-query blocks per wave: 1 for nq <= 128 (HBM-bound regime), else 2
-uint32_t filter_nb(uint32_t nq) { return nq <= 128 ? 1u : 2u; }
+template <int DIM>
+nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
+                                 uint32_t nq_pad, uint32_t cap) {
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * (FILTER_ROWS * DIM + 4 * 1024);
+  const void* fn = reinterpret_cast<const void*>(filter_i8_kernel<DIM>);
+  if (!c->lds_attr_set.count(fn)) {
+    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    c->lds_attr_set.insert(fn);
+  }
+  uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
+  if (nwg == 0) nwg = QT;
+  nvdb_status st;
+  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+  if ((st = ensure(c, c->hitcnt, static_cast<size_t>(nwg) * 4 * 4))) return st;
+  const signed char* qhi = static_cast<const signed char*>(c->q16.p);
+  const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * DIM;
+  filter_i8_kernel<DIM><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
+                                              static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
+                                              static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
+                                              static_cast<uint32_t*>(c->hitcnt.p));
+  HIPCHK(c, hipGetLastError());
+  scatter_hits_kernel<<<nwg * 4, 64, 0, s>>>(static_cast<const Hit*>(c->hitlog.p), static_cast<const uint32_t*>(c->hitcnt.p),
+                                             static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap,
+                                             static_cast<uint32_t*>(c->overflow.p), static_cast<uint32_t*>(c->misc.p) + 1);
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+// NB = 32-query blocks per wave: fp16: 1 for nq <= 128 (HBM-bound regime), else 2; int8: always 1 (two planes)
+uint32_t filter_nb(const nvdb_hip_ctx* c, uint32_t nq) { return (c->dtype == NVDB_DTYPE_I8 || nq <= 128) ? 1u : 2u; }
 
 nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT, uint32_t cap) {
-  const uint32_t nb = filter_nb(nq);
+  const uint32_t nb = filter_nb(c, nq);
+  if (c->dtype == NVDB_DTYPE_I8) {
+    const uint32_t nq_pad = QT * 128u;
+    if (c->dim == 768) return launch_filter_i8_dim<768>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->dim == 512) return launch_filter_i8_dim<512>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->dim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    return fail(c, NVDB_ERR_UNSUPPORTED, "int8 filter kernel: unsupported dim");
+  }
   if (c->dim == 768) return nb == 1 ? launch_filter_dim<768, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<768, 2>(c, s, row_lo, row_hi, nq, QT, cap);
   if (c->dim == 384) return nb == 1 ? launch_filter_dim<384, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<384, 2>(c, s, row_lo, row_hi, nq, QT, cap);
   return fail(c, NVDB_ERR_UNSUPPORTED, "filter kernel: unsupported dim");
@@ -279,12 +316,12 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t n = static_cast<uint32_t>(c->n);
   int path = force_path ? force_path : static_cast<int>(c->opt_path);
   if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
-  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16 corpus with dim 768 or 384");
+  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16 corpus with dim 768/384 or an int8 corpus with dim 768/512/256");
 
   uint32_t cap = c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : (nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
   if (cap < 4 * k_eff) cap = std::min<uint32_t>(SELECT_MAX_CAP, 4 * k_eff);
-  const uint32_t QPB = 128u * filter_nb(nq);                 // queries per filter workgroup
+  const uint32_t QPB = 128u * filter_nb(c, nq);              // queries per filter workgroup
   const uint32_t QT = (nq + QPB - 1) / QPB;
   const uint32_t nq_pad = QT * QPB;
 
@@ -316,9 +353,15 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   if ((st = ensure(c, c->qinv, nq_pad * 4))) return st;
   if ((st = ensure(c, c->ebound, nq_pad * 4))) return st;
   if ((st = ensure(c, c->slack, nq_pad * 4))) return st;
-  prep_q16_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->max_norm, FILTER_REL_F16, static_cast<_Float16*>(c->q16.p),
-                                         static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
-                                         static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
+  if (c->dtype == NVDB_DTYPE_I8)
+    prep_q8_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->max_norm, static_cast<signed char*>(c->q16.p),
+                                          static_cast<signed char*>(c->q16.p) + static_cast<size_t>(nq_pad) * c->dim,
+                                          static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
+                                          static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
+  else
+    prep_q16_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->max_norm, FILTER_REL_F16, static_cast<_Float16*>(c->q16.p),
+                                           static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
+                                           static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
   HIPCHK(c, hipGetLastError());
   const float* slack = static_cast<const float*>(c->slack.p);
   // bootstrap chunk [0,r) on the exact kernel; r is a multiple of the 32-row MFMA tile so that every
@@ -336,7 +379,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     if (acct) {
       HIPCHK(c, hipEventCreate(&kl.e0)); HIPCHK(c, hipEventCreate(&kl.e1));
       kl.flops = 2.0 * nq * static_cast<double>(hi - r) * c->dim;          // algorithmic: real queries only
-      kl.bytes = static_cast<double>(hi - r) * c->dim * 2.0;               // corpus rows read once
+      kl.bytes = static_cast<double>(hi - r) * (c->dim * static_cast<double>(bpe_of(c->dtype)) + (c->dtype == NVDB_DTYPE_I8 ? 4.0 : 0.0));   // rows read once
       HIPCHK(c, hipEventRecord(kl.e0, s));
     }
     if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev), s)); }

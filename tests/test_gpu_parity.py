@@ -134,6 +134,27 @@ def test_filter_path_f16_matches_oracle(ctx, oracle, nq, k):
     _check_against_oracle(oracle, base, po.DT_F16, None, queries, ids, sc, k, f"filter/nq{nq}/k{k}")
 
 
+@pytest.mark.parametrize("nq,k,d", [(64, 10, 768), (300, 10, 768), (40, 64, 256)])
+def test_filter_path_int8_matches_oracle(ctx, oracle, nq, k, d):
+    """int8(+scale) corpus on the integer matrix cores (two-plane int8 query), exact rescore in the
+    reference's dequantise-and-FMA order (simd_dot.cpp:160-199): ids and score bits must match."""
+    n = 120000 + 7
+    ctx.generate_corpus(SEED + 40, n, d, nvdb_amd.DT_I8)
+    base, scales = nvdb_amd.synth_corpus(SEED + 40, 0, n, d, nvdb_amd.DT_I8)
+    queries = nvdb_amd.synth_rows_f32(SEED + 41, 0, nq, d)
+    queries[1] *= np.float32(123.0)
+    queries[2, :3] *= np.float32(25.0)
+    res = {}
+    for path in (2, 1):
+        ctx.set_option("path", path)
+        res[path] = ctx.search_batch(queries, k)
+        st = ctx.stats()
+        assert st["path"] == path and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    ctx.set_option("path", 0)
+    assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1].view(np.uint32), res[2][1].view(np.uint32))
+    _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[2][0], res[2][1], k, f"filter-i8/nq{nq}")
+
+
 def test_filter_path_scaled_and_skewed_queries(ctx, oracle):
     """Query scale must not matter (per-query power-of-two prescale), nor heavy-tailed elements."""
     n, d, nq, k = 100000, 768, 48, 10
