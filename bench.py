@@ -230,11 +230,19 @@ def main():
         sec = kt["ms"] * 1e-3
         ach = kt["flops"] / sec / 1e12
         peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_I8_TOPS
-        # the int8 kernel issues TWO integer MFMAs per query block (hi/lo planes): algorithmic ops stay 2*B*N*d
-        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if args.dtype == "f16" else "TOP/s", "frac": ach / peak,
-                           "traffic": None, "kernel": "filter_f16_kernel<768>" if args.dtype == "f16" else "filter_i8_kernel<768>", "launches": kt["launches"],
-                           "avg_launch_ms": kt["ms"] / kt["launches"], "kernel_time_share": kt["ms"] / (elapsed * 1e3),
-                           "hbm_GBps_algorithmic": kt["bytes"] / sec / 1e9, "hbm_frac": kt["bytes"] / sec / 1e9 / PEAK_HBM_GBPS}
+        kname = ("filter_f16_kernel<768>" if args.dtype == "f16" else "filter_i8_kernel<768>")
+        gbps = kt["bytes"] / sec / 1e9
+        # ridge point: intensity = 2*B*dim flop per row / row bytes  vs  peak flop / peak bytes
+        hbm_bound = (2.0 * B * D / bpr) < (peak * 1e12 / (PEAK_HBM_GBPS * 1e9))
+        common = {"traffic": None, "kernel": kname, "launches": kt["launches"], "avg_launch_ms": kt["ms"] / kt["launches"],
+                  "kernel_time_share": kt["ms"] / (elapsed * 1e3), "mfma_T_per_s": ach, "mfma_frac": ach / peak,
+                  "hbm_GBps_algorithmic": gbps, "hbm_frac": gbps / PEAK_HBM_GBPS}
+        if hbm_bound:
+            out["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, **common}
+        else:
+            # the int8 kernel issues TWO integer MFMAs per query block (hi/lo planes): algorithmic ops stay 2*B*N*d
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if args.dtype == "f16" else "TOP/s",
+                               "frac": ach / peak, **common}
     else:
         out["roofline"] = None
 
