@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=96)
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 exact kernel, 2 MFMA filter")
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (nvdb_hip_set_option), repeatable")
     ap.add_argument("--sweep", default="", help="comma list of extra batch sizes to time (N=1 only), e.g. 1,16,64,256")
     return ap.parse_args()
 
@@ -134,6 +135,9 @@ def main():
     ctx = nvdb_amd.HipContext(local_rank)
     ctx.generate_corpus(SEED, hi - lo, D, dt, row_base=lo)     # one-time, excluded like the reference's base H2D
     ctx.set_option("path", args.path)
+    for kv in args.opt:
+        key, val = kv.split("=")
+        ctx.set_option(key, int(val))
 
     # query batches: independent synthetic rows (no self-match), resident in HBM before timing
     nbatches = 4

@@ -326,6 +326,172 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two speculative stages before exit
 }
 
+// ------------------------------------------------------------------------------------------------
+// Same kernel on v_mfma_f32_16x16x32_f16 (64 queries per wave = 4 blocks of 16, tile = 2 blocks of 16
+// rows, 24 k-steps of 32): identical bytes, registers (384 for B, 32 accumulators) and LDS reads, twice
+// as many half-size MFMAs.  The chip holds a higher clock on this shape under matrix load
+// (MI355X_MICROARCH.md "DVFS give-back" item 7), which is the only reason this variant exists.
+// ------------------------------------------------------------------------------------------------
+#define NVDB_MFMA16_ZERO_A(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b))
+#define NVDB_MFMA16_ZERO_V(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b))
+#define NVDB_MFMA16_ACC_A(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
+#define NVDB_MFMA16_ACC_V(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+
+template <int DIM, int RING = 6>
+__global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
+    const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
+    uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
+    const float* __restrict__ qinv, Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt) {
+  constexpr int KS = DIM / 32;                     // k-steps of 32
+  constexpr int ROW_BYTES = DIM * 2;
+  constexpr int STAGE_BYTES = FILTER_ROWS * ROW_BYTES;
+  constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / 4;
+  constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
+  constexpr int NFRAG = 4 * KS, NFRAG_A = NFRAG < 64 ? NFRAG : 64, NFRAG_V = NFRAG - NFRAG_A;
+  constexpr int NREAD = 2 * KS;                    // A fragments per tile (2 row blocks x KS)
+  static_assert(DIM % 128 == 0 && PIECES % 4 == 0 && NREAD % PPW == 0, "shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x15 = lane & 15, g4 = lane >> 4;
+  const uint32_t wave_gid = blockIdx.x * 4 + wave;
+
+  const uint32_t nwg = gridDim.x, b = blockIdx.x;
+  const uint32_t S = nwg / QT;
+  uint32_t stream, qt;
+  if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
+  else { qt = b % QT; stream = b / QT; }
+  const uint32_t tiles_total = (row_hi - row_lo) / FILTER_ROWS;
+  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
+  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const uint32_t NT = t_hi - t_lo;
+  if (NT == 0) { if (lane == 0) hitcnt[wave_gid] = 0; return; }
+
+  // B fragment f = nb*KS + s: query block nb (16 queries), k-step s; lane (x15,g4) holds
+  // q16[query x15 of the block][32 s + 8 g4 .. +8]
+  const uint32_t qbase = qt * 256u + wave * 64u;
+  float4_t bqa[NFRAG_A];
+  float4_t bqv[NFRAG_V > 0 ? NFRAG_V : 1];
+#pragma unroll
+  for (int f = 0; f < NFRAG; ++f) {
+    const int nb = f / KS, s = f % KS;
+    const float4_t v = *reinterpret_cast<const float4_t*>(q16 + static_cast<uint64_t>(qbase + nb * 16 + x15) * DIM + 32 * s + 8 * g4);
+    if (f < NFRAG_A) bqa[f] = v; else bqv[f - NFRAG_A] = v;
+  }
+#pragma unroll
+  for (int f = 0; f < NFRAG_A; ++f) asm volatile("" ::"a"(bqa[f]));
+#pragma unroll
+  for (int f = 0; f < NFRAG_V; ++f) asm volatile("" ::"v"(bqv[f]));
+  float thr_s[4], inv_s[4];
+  uint32_t qid[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    qid[nb] = qbase + nb * 16 + x15;
+    const bool real = qid[nb] < nq;
+    thr_s[nb] = real ? thr[qid[nb]] * qscale[qid[nb]] : __builtin_huge_valf();
+    inv_s[nb] = real ? qinv[qid[nb]] : 0.f;
+    asm volatile("" ::"v"(thr_s[nb]), "v"(inv_s[nb]));
+  }
+  const bool wave_has_queries = qbase < nq;
+
+  uint32_t src_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const uint32_t P = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
+    const uint32_t r = P / CHUNKS_PER_ROW, cpos = P % CHUNKS_PER_ROW;
+    src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
+  }
+  // A fragment (mb,s): lane (x15,g4) reads chunk 4s+g4 of row 16mb+x15, stored at position (4s+g4)^x15:
+  //   a16 ^ ((s&3) << 6)  +  256*(s>>2)  +  16*ROW_BYTES*mb
+  const uint32_t a16 = static_cast<uint32_t>(x15) * ROW_BYTES + ((static_cast<uint32_t>(g4) ^ static_cast<uint32_t>(x15)) << 4);
+
+  const char* gbase = reinterpret_cast<const char*>(rows);
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
+  auto tile_ptr = [&](uint32_t t_rel) -> const char* {
+    const uint32_t t = t_lo + (t_rel < NT ? t_rel : NT - 1);
+    return gbase + static_cast<uint64_t>(row_lo + t * FILTER_ROWS) * ROW_BYTES;
+  };
+  auto issue_piece = [&](const char* tile, uint32_t buf, int i) {
+    glds16(src_off[i], tile, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
+  };
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) issue_piece(tile_ptr(0), 0, i);
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) issue_piece(tile_ptr(1), 1, i);
+
+  constexpr int PIECE_EVERY = NREAD / PPW;
+  uint32_t wcnt = 0;
+  Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
+
+  for (uint32_t t = 0; t < NT; ++t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* next_tile = tile_ptr(t + 2);
+    const uint32_t next_buf = (t + 2) % FILTER_STAGES;
+    const char* stage = smem + (t % FILTER_STAGES) * STAGE_BYTES;
+    if (!wave_has_queries) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) issue_piece(next_tile, next_buf, i);
+      continue;
+    }
+    auto read_a = [&](int u) -> float4_t {        // u = 2*s + mb
+      const int s = u >> 1, mb = u & 1;
+      return *reinterpret_cast<const float4_t*>(stage + (a16 ^ ((s & 3) << 6)) + (s >> 2) * 256 + mb * 16 * ROW_BYTES);
+    };
+    float4_t ar[RING];
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u) ar[u] = read_a(u);
+    float4_t acc[2][4];
+#pragma unroll
+    for (int u = 0; u < NREAD; ++u) {
+      if (u + RING - 1 < NREAD) ar[(u + RING - 1) % RING] = read_a(u + RING - 1);
+      const float4_t a = ar[u % RING];
+      const int s = u >> 1, mb = u & 1;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int f = nb * KS + s;
+        if (s == 0) {
+          if (f < NFRAG_A) NVDB_MFMA16_ZERO_A(acc[mb][nb], a, bqa[f < NFRAG_A ? f : 0]);
+          else NVDB_MFMA16_ZERO_V(acc[mb][nb], a, bqv[f >= NFRAG_A ? f - NFRAG_A : 0]);
+        } else {
+          if (f < NFRAG_A) NVDB_MFMA16_ACC_A(acc[mb][nb], a, bqa[f < NFRAG_A ? f : 0]);
+          else NVDB_MFMA16_ACC_V(acc[mb][nb], a, bqv[f >= NFRAG_A ? f - NFRAG_A : 0]);
+        }
+      }
+      if (u % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_tile, next_buf, u / PIECE_EVERY);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                                          "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+    bool any = false;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) any |= (acc[mb][nb][r] >= thr_s[nb]);
+    if (__builtin_amdgcn_ballot_w64(any)) {
+      const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[mb][nb][r];
+            const bool hit = v >= thr_s[nb];
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            if (m) {
+              const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+              if (hit && idx < FILTER_LOGCAP) mylog[idx] = Hit{v * inv_s[nb], row0 + 16 * mb + 4 * g4 + r, qid[nb], 0u};
+              wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
+            }
+          }
+    }
+  }
+  if (lane == 0) hitcnt[wave_gid] = wcnt;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // File every logged survivor under its query: cand[qid][slot] with slot from an atomic counter.
 // grid = number of wave logs, block = 64.
 __global__ __launch_bounds__(64) void scatter_hits_kernel(const Hit* __restrict__ hitlog, const uint32_t* __restrict__ hitcnt,

@@ -73,6 +73,7 @@ struct nvdb_hip_ctx {
   struct KLaunch { hipEvent_t e0, e1; double flops, bytes; };
   std::vector<KLaunch> klaunch;
   int64_t opt_time_kernels = 0;
+  int64_t opt_mfma16 = 0;                          // 1: use the 16x16x32 MFMA build for 256-query tiles
   std::set<const void*> lds_attr_set;              // kernels whose dynamic-LDS limit was raised on this device
 };
 
@@ -237,7 +238,8 @@ template <int DIM, int NB>
 nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
                               uint32_t cap) {
   constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * DIM * 2;
-  const void* fn = reinterpret_cast<const void*>(filter_f16_kernel<DIM, NB>);
+  const bool m16 = (NB == 2) && c->opt_mfma16;
+  const void* fn = m16 ? reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM>) : reinterpret_cast<const void*>(filter_f16_kernel<DIM, NB>);
   if (!c->lds_attr_set.count(fn)) {
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     c->lds_attr_set.insert(fn);
@@ -247,10 +249,16 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
   nvdb_status st;
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
   if ((st = ensure(c, c->hitcnt, static_cast<size_t>(nwg) * 4 * 4))) return st;
-  filter_f16_kernel<DIM, NB><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), row_lo, row_hi,
-                                                   static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
-                                                   static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
-                                                   static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p));
+  if (m16)
+    filter_f16_m16_kernel<DIM><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), row_lo, row_hi,
+                                                     static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
+                                                     static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
+                                                     static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p));
+  else
+    filter_f16_kernel<DIM, NB><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), row_lo, row_hi,
+                                                     static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
+                                                     static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
+                                                     static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p));
   HIPCHK(c, hipGetLastError());
   scatter_hits_kernel<<<nwg * 4, 64, 0, s>>>(static_cast<const Hit*>(c->hitlog.p), static_cast<const uint32_t*>(c->hitcnt.p),
                                              static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap,
@@ -545,6 +553,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "chunk0_rows") { if (value < 256) return fail(c, NVDB_ERR_INVALID, "chunk0_rows must be >= 256"); c->opt_chunk0 = value; }
   else if (k == "cand_cap") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "cand_cap out of range"); c->opt_cap = value; }
   else if (k == "time_kernels") { c->opt_time_kernels = value ? 1 : 0; }
+  else if (k == "mfma16") { c->opt_mfma16 = value ? 1 : 0; }
   else if (k == "chunk_growth") { if (value < 2 || value > 64) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be in [2,64]"); c->opt_growth = value; }
   else if (k == "min_filter_batch") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "min_filter_batch must be >= 1"); c->opt_min_filter_batch = value; }
   else return fail(c, NVDB_ERR_INVALID, "unknown option: " + k);

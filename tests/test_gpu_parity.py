@@ -134,6 +134,25 @@ def test_filter_path_f16_matches_oracle(ctx, oracle, nq, k):
     _check_against_oracle(oracle, base, po.DT_F16, None, queries, ids, sc, k, f"filter/nq{nq}/k{k}")
 
 
+def test_filter_path_mfma16_variant_matches_default(ctx, oracle):
+    """The 16x16x32-MFMA build of the filter kernel must give the same bits as the 32x32x16 build."""
+    n, d, nq, k = 90000 + 5, 768, 300, 10
+    ctx.generate_corpus(SEED + 50, n, d, nvdb_amd.DT_F16)
+    base, _ = nvdb_amd.synth_corpus(SEED + 50, 0, n, d, nvdb_amd.DT_F16)
+    queries = nvdb_amd.synth_rows_f32(SEED + 51, 0, nq, d)
+    ctx.set_option("path", 2)
+    res = {}
+    for m16 in (0, 1):
+        ctx.set_option("mfma16", m16)
+        res[m16] = ctx.search_batch(queries, k)
+        st = ctx.stats()
+        assert st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    ctx.set_option("mfma16", 0)
+    ctx.set_option("path", 0)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+    _check_against_oracle(oracle, base, po.DT_F16, None, queries, res[1][0], res[1][1], k, "mfma16")
+
+
 @pytest.mark.parametrize("nq,k,d", [(64, 10, 768), (300, 10, 768), (40, 64, 256)])
 def test_filter_path_int8_matches_oracle(ctx, oracle, nq, k, d):
     """int8(+scale) corpus on the integer matrix cores (two-plane int8 query), exact rescore in the
