@@ -73,7 +73,7 @@ struct nvdb_hip_ctx {
   struct KLaunch { hipEvent_t e0, e1; double flops, bytes; };
   std::vector<KLaunch> klaunch;
   int64_t opt_time_kernels = 0;
-  int64_t opt_mfma16 = 0;                          // 1: use the 16x16x32 MFMA build for 256-query tiles
+  int64_t opt_mfma16 = 1;                          // 1: use the 16x16x32 MFMA build for 256-query tiles
   std::set<const void*> lds_attr_set;              // kernels whose dynamic-LDS limit was raised on this device
 };
 
