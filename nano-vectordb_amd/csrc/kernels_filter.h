@@ -114,7 +114,7 @@ __device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_
 
 // One survivor of the filter, logged by the wave that found it (16 bytes, one dwordx4 store).
 struct Hit { float score; uint32_t row; uint32_t qid; uint32_t pad; };
-constexpr uint32_t FILTER_LOGCAP = 256;            // entries per wave and launch
+constexpr uint32_t FILTER_LOGCAP = 512;            // entries per wave and launch
 
 // VAR selects timing-only ablation builds (results are wrong for VAR != 0; used by
 // nvdb_hip_debug_filter_variant): 1 = no direct-to-LDS loads in the loop, 2 = 1 + no barrier,
@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
   // tile t_rel of this stream (clamped: past-the-end tiles re-load the last one, harmlessly)
   auto tile_ptr = [&](uint32_t t_rel) -> const char* {
-    const uint32_t t = t_lo + (t_rel < NT ? t_rel : NT - 1);
+    uint32_t t = t_lo + (t_rel < NT ? t_rel : NT - 1);
+    if constexpr (VAR == 6) t = t_lo + (t_rel & 7u);          // ablation: 8 tiles per stream, L2-resident
     return gbase + static_cast<uint64_t>(row_lo + t * FILTER_ROWS) * ROW_BYTES;
   };
   auto issue_piece = [&](const char* tile, uint32_t buf, int i) {

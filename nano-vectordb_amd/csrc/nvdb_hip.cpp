@@ -61,7 +61,7 @@ struct nvdb_hip_ctx {
   void* pin = nullptr; size_t pin_bytes = 0;       // pinned staging
 
   // options
-  int64_t opt_path = 0, opt_chunk0 = 4096, opt_cap = 0, opt_min_filter_batch = 1, opt_growth = 4;
+  int64_t opt_path = 0, opt_chunk0 = 512, opt_cap = 0, opt_min_filter_batch = 1, opt_growth = 8;
 
   // state of the last search
   nvdb_hip_scan_stats stats{};
@@ -718,6 +718,7 @@ nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* c, int variant, uint32_t
     case 3: NVDB_DBG_LAUNCH(3, 4) break;
     case 5: NVDB_DBG_LAUNCH(5, 4) break;
     case 6: NVDB_DBG_LAUNCH(0, 6) break;
+    case 10: NVDB_DBG_LAUNCH(6, 6) break;
     case 7: NVDB_DBG_LAUNCH(0, 8) break;
     case 8: NVDB_DBG_LAUNCH(0, 3) break;
     case 9: NVDB_DBG_LAUNCH(0, 12) break;

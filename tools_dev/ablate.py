@@ -9,7 +9,7 @@ ctx = nvdb_amd.HipContext(0)
 ctx.generate_corpus(20240613, n, 768, nvdb_amd.DT_F16)
 lib = nvdb_amd.load_library()
 lib.nvdb_hip_debug_filter_variant.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
-names = {0: "normal", 1: "no glds", 2: "no glds, no barrier", 3: "no MFMA", 4: "no epilogue", 5: "no LDS reads", 6: "ring 6", 7: "ring 8", 8: "ring 3", 9: "ring 12"}
+names = {0: "normal", 1: "no glds", 2: "no glds, no barrier", 3: "no MFMA", 4: "no epilogue", 5: "no LDS reads", 6: "ring 6", 7: "ring 8", 8: "ring 3", 9: "ring 12", 10: "L2-resident corpus (8 tiles/stream), ring 6"}
 variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(names)
 for nq in (1024, 256):
     q = nvdb_amd.synth_rows_f32(1, 0, nq, 768)
