@@ -122,6 +122,13 @@ constexpr uint32_t FILTER_LOGCAP = 512;            // entries per wave and launc
 // NB = 32-query blocks per wave: 2 -> 256 queries per workgroup (MFMA-bound batches), 1 -> 128 queries
 // per workgroup (half the MFMA work per streamed byte: the HBM-bound regime, nq <= 128).
 // RING = A fragments in flight LDS -> VGPR.
+// same, with a full 64-bit per-lane source address (row gathers whose offsets exceed 32 bits)
+__device__ __forceinline__ void glds16_v(const void* gptr, uint32_t lds_off) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds_off) : "memory");
+}
+
 template <int DIM, int NB, int VAR = 0, int RING = 6>
 __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,

@@ -73,6 +73,7 @@ struct nvdb_hip_ctx {
   struct KLaunch { hipEvent_t e0, e1; double flops, bytes; };
   std::vector<KLaunch> klaunch;
   int64_t opt_time_kernels = 0;
+  int64_t opt_refine_v2 = 1;                       // 1: LDS-staged coalesced gather in the refine kernel
   int64_t opt_mfma16 = 1;                          // 1: use the 16x16x32 MFMA build for 256-query tiles
   std::set<const void*> lds_attr_set;              // kernels whose dynamic-LDS limit was raised on this device
 };
@@ -554,6 +555,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "cand_cap") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "cand_cap out of range"); c->opt_cap = value; }
   else if (k == "time_kernels") { c->opt_time_kernels = value ? 1 : 0; }
   else if (k == "mfma16") { c->opt_mfma16 = value ? 1 : 0; }
+  else if (k == "refine_v2") { c->opt_refine_v2 = value ? 1 : 0; }
   else if (k == "chunk_growth") { if (value < 2 || value > 64) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be in [2,64]"); c->opt_growth = value; }
   else if (k == "min_filter_batch") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "min_filter_batch must be >= 1"); c->opt_min_filter_batch = value; }
   else return fail(c, NVDB_ERR_INVALID, "unknown option: " + k);
@@ -790,6 +792,20 @@ static nvdb_status refine_args(nvdb_hip_ctx* c, const void* q, const void* cand,
 static nvdb_status launch_refine(nvdb_hip_ctx* c, hipStream_t s, const float* dq, const uint32_t* dc, uint32_t Q, uint32_t R,
                                  uint32_t K, uint32_t* doi, float* dod) {
   const bool al = aligned_rows(c->dtype, c->dim);
+  // v2 (coalesced gather through LDS): whole 16-byte steps only (f16: dim % 8 == 0, f32: dim % 4 == 0)
+  if (al && c->opt_refine_v2 && static_cast<uint64_t>(c->dim) * bpe_of(c->dtype) >= 256) {
+    constexpr size_t lds = 4 * 2 * 64 * 256;
+    const void* fn = c->dtype == NVDB_DTYPE_F16 ? reinterpret_cast<const void*>(refine_l2_lds_kernel<DT_F16>)
+                                                : reinterpret_cast<const void*>(refine_l2_lds_kernel<DT_F32>);
+    if (!c->lds_attr_set.count(fn)) {
+      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      c->lds_attr_set.insert(fn);
+    }
+    if (c->dtype == NVDB_DTYPE_F16) refine_l2_lds_kernel<DT_F16><<<Q, 256, lds, s>>>(c->rows, c->n, c->dim, dq, dc, R, K, doi, dod);
+    else refine_l2_lds_kernel<DT_F32><<<Q, 256, lds, s>>>(c->rows, c->n, c->dim, dq, dc, R, K, doi, dod);
+    HIPCHK(c, hipGetLastError());
+    return NVDB_OK;
+  }
   if (c->dtype == NVDB_DTYPE_F16) {
     if (al) refine_l2_kernel<DT_F16, true><<<Q, 256, 0, s>>>(c->rows, c->n, c->dim, dq, dc, R, K, doi, dod);
     else refine_l2_kernel<DT_F16, false><<<Q, 256, 0, s>>>(c->rows, c->n, c->dim, dq, dc, R, K, doi, dod);
