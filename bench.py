@@ -177,7 +177,8 @@ def main():
         # the reference's CPU scores of the returned rows (oracle dot on rows copied back from HBM)
         import pyoracle as po
         orc = po.Oracle()
-        step(0)
+        # local search only (no collective here: the other ranks are not in this branch)
+        ctx.search_batch_dev(qdev[:B].data_ptr(), B, K, out_ids.data_ptr(), out_sc.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         fi, fs = out_ids[:8].cpu().numpy().astype(np.uint64), out_sc[:8].cpu().numpy()
         ctx.set_option("path", 1)
