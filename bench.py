@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-sample-queries", type=int, default=96)
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 exact kernel, 2 MFMA filter")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (nvdb_hip_set_option), repeatable")
+    ap.add_argument("--verify-merge", action="store_true", help="N>1: rank 0 also searches the unsharded corpus and compares the merged lists")
     ap.add_argument("--sweep", default="", help="comma list of extra batch sizes to time (N=1 only), e.g. 1,16,64,256")
     return ap.parse_args()
 
@@ -120,12 +121,20 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # NVDB_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank uses device 0 and the exchange goes through
+    # gloo on host copies -- same sharding / all-gather / merge logic, no RCCL (RCCL refuses two ranks on one device).
+    share_gpu = os.environ.get("NVDB_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     dt = nvdb_amd.DT_F16 if args.dtype == "f16" else nvdb_amd.DT_I8
     bpr = args.dim * 2 if args.dtype == "f16" else args.dim + 4      # algorithmic bytes per corpus row
@@ -156,8 +165,16 @@ def main():
         q = qdev[(i % nbatches) * B:(i % nbatches) * B + batch]
         ctx.search_batch_dev(q.data_ptr(), batch, K, out_ids.data_ptr(), out_sc.data_ptr(), stream)
         if world > 1:
-            dist.all_gather_into_tensor(g_ids, out_ids)       # RCCL over xGMI: B*k*(8+4) bytes per rank
-            dist.all_gather_into_tensor(g_sc, out_sc)
+            if share_gpu:
+                hi_, hs_ = out_ids.cpu(), out_sc.cpu()
+                ci, cs = torch.empty((world * B, K), dtype=torch.int64), torch.empty((world * B, K), dtype=torch.float32)
+                dist.all_gather_into_tensor(ci, hi_)
+                dist.all_gather_into_tensor(cs, hs_)
+                g_ids.copy_(ci)
+                g_sc.copy_(cs)
+            else:
+                dist.all_gather_into_tensor(g_ids, out_ids)   # RCCL over xGMI: B*k*(8+4) bytes per rank
+                dist.all_gather_into_tensor(g_sc, out_sc)
             ctx.merge_topk_dev(g_ids.data_ptr(), g_sc.data_ptr(), world, batch, K, m_ids.data_ptr(), m_sc.data_ptr(), stream)
 
     def barrier():
@@ -200,6 +217,21 @@ def main():
             raise SystemExit("parity self-check failed: filter path != exact path / oracle scores")
     barrier()
 
+    merge_check = None
+    if world > 1 and args.verify_merge:
+        step(0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            full = nvdb_amd.HipContext(local_rank)
+            full.generate_corpus(SEED, N, D, dt, row_base=0)
+            fi, fs = full.search_batch(qhost[:B], K)
+            full.close()
+            mi, ms_ = m_ids.cpu().numpy().astype(np.uint64), m_sc.cpu().numpy()
+            merge_check = bool(np.array_equal(mi, fi) and np.array_equal(ms_.view(np.uint32), fs.view(np.uint32)))
+            if not merge_check:
+                raise SystemExit("sharded + merged result differs from the unsharded search")
+        barrier()
+
     # ---- timed region ---------------------------------------------------------------------------------
     ctx.set_option("time_kernels", 1)
     barrier()
@@ -227,7 +259,7 @@ def main():
                    "rows_per_gpu": hi - lo, "batch": B, "k": K, "dim": D,
                    "parallelism": "1 GPU" if world == 1 else f"corpus row-sharded x{world}, RCCL all-gather of per-shard top-k"},
         "effective_hbm_GBps": (N * bpr / 1e9) / (ms_per_step * 1e-3),          # corpus bytes / pass time, all GPUs
-        "parity": parity,
+        "parity": parity, "merge_check": merge_check,
         "scan": {"path": stats["path"], "chunks": stats["chunks"], "candidates_per_query": stats["candidates"] / max(B, 1),
                  "bound_violations": stats["bound_violations"], "overflow_queries": stats["overflow_queries"]},
     }
