@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(
 //   mode 0: thr[q] = (k-th score) - slack[q]; keep every entry with score >= thr (all of the top-k
 //           plus whatever lies inside the filter's error band); write the list back compacted;
 //   mode 1: emit the final top-k (global ids, padded with UINT64_MAX / -inf).
-// grid = nq, block = 256, dynamic LDS = cap * 8 bytes.
+//   mode 2: like mode 0 but the list is emptied afterwards (thresholds from bootstrap tile maxima).
+// grid = nq, block = 64..256 (any multiple of 64), dynamic LDS = cap * 8 bytes.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void select_kernel(
     Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t k, const float* __restrict__ slack,
@@ -306,17 +307,17 @@ __global__ __launch_bounds__(256) void select_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Cand* e = reinterpret_cast<Cand*>(smem_raw);
   __shared__ uint32_t s_keep;
-  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
   uint32_t m = cnt[q];
   if (m > cap) { if (tid == 0) overflow[q] = 1u; m = cap; }
   uint32_t M2 = 1;
   while (M2 < m) M2 <<= 1;
   Cand* mine = cand + static_cast<uint64_t>(q) * cap;
-  for (uint32_t i = tid; i < M2; i += 256) e[i] = (i < m) ? mine[i] : Cand{NEG_INF, 0xFFFFFFFFu};
+  for (uint32_t i = tid; i < M2; i += nth) e[i] = (i < m) ? mine[i] : Cand{NEG_INF, 0xFFFFFFFFu};
   __syncthreads();
   for (uint32_t size = 2; size <= M2; size <<= 1) {
     for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      for (uint32_t i = tid; i < (M2 >> 1); i += 256) {
+      for (uint32_t i = tid; i < (M2 >> 1); i += nth) {
         const uint32_t a = 2 * i - (i & (stride - 1));   // index with bit `stride` clear
         const uint32_t b = a + stride;
         const bool desc = ((a & size) == 0);             // first half of each 2*size block: best first
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void select_kernel(
   }
   if (mode == 1) {
     const uint32_t c = m < k ? m : k;
-    for (uint32_t j = tid; j < out_k; j += 256) {
+    for (uint32_t j = tid; j < out_k; j += nth) {
       const bool have = j < c;
       out_ids[static_cast<uint64_t>(q) * out_k + j] = have ? (row_base + e[j].row) : ~0ull;
       out_scores[static_cast<uint64_t>(q) * out_k + j] = have ? e[j].score : NEG_INF;
@@ -342,13 +343,13 @@ __global__ __launch_bounds__(256) void select_kernel(
   if (tid == 0) s_keep = 0;
   __syncthreads();
   uint32_t local = 0;
-  if (sl > 0.f) { for (uint32_t i = tid; i < m; i += 256) local += (e[i].score >= t) ? 1u : 0u; }
-  else { for (uint32_t i = tid; i < m; i += 256) local += (i < k) ? 1u : 0u; }
+  if (sl > 0.f) { for (uint32_t i = tid; i < m; i += nth) local += (e[i].score >= t) ? 1u : 0u; }
+  else { for (uint32_t i = tid; i < m; i += nth) local += (i < k) ? 1u : 0u; }
   if (local) atomicAdd(&s_keep, local);
   __syncthreads();
   const uint32_t keep = s_keep;                          // sorted list -> the kept ones are a prefix
-  for (uint32_t i = tid; i < keep; i += 256) mine[i] = e[i];
-  if (tid == 0) { cnt[q] = keep; thr[q] = t; }
+  for (uint32_t i = tid; i < keep; i += nth) mine[i] = e[i];
+  if (tid == 0) { cnt[q] = (mode == 2) ? 0u : keep; thr[q] = t; }
 }
 
 // ------------------------------------------------------------------------------------------------

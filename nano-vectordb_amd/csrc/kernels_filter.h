@@ -133,7 +133,8 @@ template <int DIM, int NB, int VAR = 0, int RING = 6>
 __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
     uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
-    const float* __restrict__ qinv, Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt) {
+    const float* __restrict__ qinv, Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt, uint32_t aux) {
+  // aux: VAR 7 (bootstrap build) only -- hitlog then points at the candidate lists and aux is their stride
   constexpr int KSTEPS = DIM / 16;                 // MFMA k-steps per tile
   constexpr int ROW_BYTES = DIM * 2;
   constexpr int STAGE_BYTES = FILTER_ROWS * ROW_BYTES;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
   const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
   const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
   const uint32_t NT = t_hi - t_lo;
-  if (NT == 0) { if (lane == 0) hitcnt[wave_gid] = 0; return; }
+  if (NT == 0) { if (VAR != 7 && lane == 0) hitcnt[wave_gid] = 0; return; }
 
   // ---- stationary operand: this wave's queries, all of K, in registers -------------------------
   // fragment f = nb*KSTEPS + s : query block nb (32 queries), k-step s.  Lane (r31,hsel) holds
@@ -296,6 +297,27 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     if constexpr (NB == 2) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
     else asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]));
 
+    if constexpr (VAR == 7) {
+      // ---- bootstrap epilogue: best row of this tile for every query -> cand[qid][tile] -----------
+      // (a lower bound generator for the first thresholds: the k-th largest of T tile maxima is <= the
+      //  k-th largest score overall; the host discards these entries after the threshold is taken and
+      //  the same rows are scanned again by the normal build, so nothing is lost or duplicated)
+      const uint32_t tile = t_lo + t;
+      const uint32_t row0b = row_lo + tile * FILTER_ROWS;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float best = acc[nb][0];
+        uint32_t brow = 0;
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { const bool gt = acc[nb][r] > best; best = gt ? acc[nb][r] : best; brow = gt ? static_cast<uint32_t>(r) : brow; }
+        uint32_t grow = row0b + (brow & 3) + 8 * (brow >> 2) + 4 * hsel;
+        const float obest = __shfl_xor(best, 32);
+        const uint32_t orow = static_cast<uint32_t>(__shfl_xor(static_cast<int>(grow), 32));
+        if (obest > best || (obest == best && orow < grow)) { best = obest; grow = orow; }
+        if (hsel == 0 && qid[nb] < nq) reinterpret_cast<Cand*>(hitlog)[static_cast<uint64_t>(qid[nb]) * aux + tile] = Cand{best * inv_s[nb], grow};
+      }
+      continue;
+    }
     // ---- epilogue: threshold filter ------------------------------------------------------------
     bool any = false;
     if constexpr (VAR == 4) {
@@ -330,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
       }
     }
   }
-  if (lane == 0) hitcnt[wave_gid] = wcnt;          // > FILTER_LOGCAP means entries were dropped
+  if (VAR != 7 && lane == 0) hitcnt[wave_gid] = wcnt;   // > FILTER_LOGCAP means entries were dropped
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two speculative stages before exit
 }
 
@@ -504,12 +526,14 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
 // grid = number of wave logs, block = 64.
 __global__ __launch_bounds__(64) void scatter_hits_kernel(const Hit* __restrict__ hitlog, const uint32_t* __restrict__ hitcnt,
                                                           Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap,
-                                                          uint32_t* __restrict__ overflow, uint32_t* __restrict__ log_overflow) {
+                                                          uint32_t* __restrict__ overflow, uint32_t* __restrict__ log_overflow,
+                                                          uint32_t n_rows) {
   const uint32_t w = blockIdx.x;
   uint32_t n = hitcnt[w];
   if (n > FILTER_LOGCAP) { if (threadIdx.x == 0) *log_overflow = 1u; n = FILTER_LOGCAP; }
   for (uint32_t i = threadIdx.x; i < n; i += 64) {
     const Hit h = hitlog[static_cast<uint64_t>(w) * FILTER_LOGCAP + i];
+    if (h.row >= n_rows) continue;                 // zero rows that pad the corpus to whole tiles
     const uint32_t slot = atomicAdd(&cnt[h.qid], 1u);
     if (slot < cap) cand[static_cast<uint64_t>(h.qid) * cap + slot] = Cand{h.score, h.row};
     else overflow[h.qid] = 1u;

@@ -73,6 +73,7 @@ struct nvdb_hip_ctx {
   struct KLaunch { hipEvent_t e0, e1; double flops, bytes; };
   std::vector<KLaunch> klaunch;
   int64_t opt_time_kernels = 0;
+  int64_t opt_mfma_boot = 1;                       // 1: threshold bootstrap on the matrix cores (fp16 corpora)
   int64_t opt_refine_v2 = 1;                       // 1: LDS-staged coalesced gather in the refine kernel
   int64_t opt_mfma16 = 1;                          // 1: use the 16x16x32 MFMA build for 256-query tiles
   std::set<const void*> lds_attr_set;              // kernels whose dynamic-LDS limit was raised on this device
@@ -205,7 +206,7 @@ nvdb_status launch_select(nvdb_hip_ctx* c, hipStream_t s, uint32_t nq, uint32_t 
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_MAX_CAP * sizeof(Cand)));
     c->lds_attr_set.insert(fn);
   }
-  select_kernel<<<nq, 256, cap * sizeof(Cand), s>>>(static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap, k, slack,
+  select_kernel<<<nq, cap <= 2048 ? 64 : 256, cap * sizeof(Cand), s>>>(static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap, k, slack,
                                                    static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->overflow.p), mode,
                                                    c->row_base, reinterpret_cast<unsigned long long*>(out_ids), out_scores, out_k);
   HIPCHK(c, hipGetLastError());
@@ -259,11 +260,11 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
     filter_f16_kernel<DIM, NB><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), row_lo, row_hi,
                                                      static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                      static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
-                                                     static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p));
+                                                     static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p), 0u);
   HIPCHK(c, hipGetLastError());
   scatter_hits_kernel<<<nwg * 4, 64, 0, s>>>(static_cast<const Hit*>(c->hitlog.p), static_cast<const uint32_t*>(c->hitcnt.p),
                                              static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap,
-                                             static_cast<uint32_t*>(c->overflow.p), static_cast<uint32_t*>(c->misc.p) + 1);
+                                             static_cast<uint32_t*>(c->overflow.p), static_cast<uint32_t*>(c->misc.p) + 1, static_cast<uint32_t>(c->n));
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -291,9 +292,35 @@ nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
   HIPCHK(c, hipGetLastError());
   scatter_hits_kernel<<<nwg * 4, 64, 0, s>>>(static_cast<const Hit*>(c->hitlog.p), static_cast<const uint32_t*>(c->hitcnt.p),
                                              static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap,
-                                             static_cast<uint32_t*>(c->overflow.p), static_cast<uint32_t*>(c->misc.p) + 1);
+                                             static_cast<uint32_t*>(c->overflow.p), static_cast<uint32_t*>(c->misc.p) + 1, static_cast<uint32_t>(c->n));
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
+}
+
+// threshold bootstrap on the matrix cores (fp16): best (score,row) of every 32-row tile of rows [0,n0) per query
+// -> cand[q][tile]; the caller then runs select(mode 2) to turn the k-th largest tile maximum into thr[q].
+template <int DIM, int NB>
+nvdb_status launch_boot_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap) {
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * DIM * 2;
+  const void* fn = reinterpret_cast<const void*>(filter_f16_kernel<DIM, NB, 7>);
+  if (!c->lds_attr_set.count(fn)) {
+    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    c->lds_attr_set.insert(fn);
+  }
+  uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
+  if (nwg == 0) nwg = QT;
+  filter_f16_kernel<DIM, NB, 7><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), 0, n0, static_cast<const _Float16*>(c->q16.p), nq, QT,
+                                                      static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
+                                                      static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->cand.p),
+                                                      static_cast<uint32_t*>(c->hitcnt.p), cap);
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap, uint32_t nb) {
+  if (c->dim == 768) return nb == 1 ? launch_boot_dim<768, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<768, 2>(c, s, n0, nq, QT, cap);
+  if (c->dim == 384) return nb == 1 ? launch_boot_dim<384, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<384, 2>(c, s, n0, nq, QT, cap);
+  return fail(c, NVDB_ERR_UNSUPPORTED, "boot kernel: unsupported dim");
 }
 
 // NB = 32-query blocks per wave: fp16: 1 for nq <= 128 (HBM-bound regime), else 2; int8: always 1 (two planes)
@@ -373,13 +400,29 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
                                            static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
   HIPCHK(c, hipGetLastError());
   const float* slack = static_cast<const float*>(c->slack.p);
-  // bootstrap chunk [0,r) on the exact kernel; r is a multiple of the 32-row MFMA tile so that every
-  // filter chunk [r,hi) is whole tiles; the ragged tail [n_al,n) also goes to the exact kernel.
-  uint32_t r = std::min<uint32_t>(n, (static_cast<uint32_t>(c->opt_chunk0) + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS);
-  const uint32_t n_al = (n <= r) ? n : r + (n - r) / FILTER_ROWS * FILTER_ROWS;
-  if ((st = launch_scan_exact(c, s, 0, r, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
-  if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
-  uint64_t size = r;
+  // Whole tiles: a corpus this library allocated is zero-padded to a multiple of 32 rows (the padded rows are
+  // dropped by scatter_hits_kernel); for an adopted corpus the ragged tail goes to the exact kernel.
+  const uint32_t n_al = c->owned ? (n + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS : n / FILTER_ROWS * FILTER_ROWS;
+  uint32_t r = 0;
+  uint64_t size;
+  const uint32_t boot_rows = 2048;
+  const bool mfma_boot = c->dtype == NVDB_DTYPE_F16 && c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
+                         boot_rows / FILTER_ROWS <= cap;
+  if (mfma_boot) {
+    // thresholds from the k-th largest of the 64 tile maxima of rows [0,2048); those rows are then scanned
+    // again by the normal build, so the bootstrap entries are discarded (select mode 2)
+    if ((st = launch_boot(c, s, boot_rows, nq, QT, cap, filter_nb(c, nq)))) return st;
+    fill_u32_kernel<<<(nq_pad + 255) / 256, 256, 0, s>>>(static_cast<uint32_t*>(c->cnt.p), boot_rows / FILTER_ROWS, nq);
+    if ((st = launch_select(c, s, nq, cap, k_eff, slack, 2, nullptr, nullptr, 0))) return st;
+    size = static_cast<uint64_t>(boot_rows) * static_cast<uint64_t>(c->opt_growth);
+  } else {
+    // bootstrap chunk [0,r) on the exact kernel; r is a multiple of the 32-row MFMA tile
+    r = std::min<uint32_t>(n_al, (static_cast<uint32_t>(c->opt_chunk0) + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS);
+    if (r > n) r = n / FILTER_ROWS * FILTER_ROWS;
+    if ((st = launch_scan_exact(c, s, 0, r, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
+    if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
+    size = static_cast<uint64_t>(r) * (static_cast<uint64_t>(c->opt_growth) - 1);
+  }
   size_t ev = 0;
   while (r < n_al) {
     const uint32_t hi = static_cast<uint32_t>(std::min<uint64_t>(n_al, static_cast<uint64_t>(r) + size));
@@ -387,8 +430,8 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     const bool acct = c->opt_time_kernels && c->klaunch.size() < 8192;
     if (acct) {
       HIPCHK(c, hipEventCreate(&kl.e0)); HIPCHK(c, hipEventCreate(&kl.e1));
-      kl.flops = 2.0 * nq * static_cast<double>(hi - r) * c->dim;          // algorithmic: real queries only
-      kl.bytes = static_cast<double>(hi - r) * (c->dim * static_cast<double>(bpe_of(c->dtype)) + (c->dtype == NVDB_DTYPE_I8 ? 4.0 : 0.0));   // rows read once
+      kl.flops = 2.0 * nq * static_cast<double>(std::min(hi, n) - r) * c->dim;   // algorithmic: real queries, real rows
+      kl.bytes = static_cast<double>(std::min(hi, n) - r) * (c->dim * static_cast<double>(bpe_of(c->dtype)) + (c->dtype == NVDB_DTYPE_I8 ? 4.0 : 0.0));   // rows read once
       HIPCHK(c, hipEventRecord(kl.e0, s));
     }
     if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev), s)); }
@@ -401,7 +444,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     r = hi;
     size = static_cast<uint64_t>(r) * (static_cast<uint64_t>(c->opt_growth) - 1);   // rows seen so far x (growth-1)
   }
-  if (n_al < n) {   // ragged tail: exact scores, pruned by the current thresholds
+  if (n_al < n) {   // ragged tail of an adopted corpus: exact scores, pruned by the current thresholds
     if ((st = launch_scan_exact(c, s, n_al, n, dev_q, nq, k_eff, static_cast<const float*>(c->thr.p), cap, 0))) return st;
     c->stats.rows_scanned += static_cast<uint64_t>(n - n_al) * QT;
   }
@@ -472,7 +515,9 @@ nvdb_status nvdb_hip_upload_corpus(nvdb_hip_ctx* c, const void* rows, const floa
   HIPCHK(c, hipSetDevice(c->device));
   free_corpus(c);
   const size_t bytes = static_cast<size_t>(n) * dim * bpe_of(dtype);
-  HIPCHK(c, hipMalloc(&c->rows, bytes + 4096));     // tail padding: 16-byte vector loads never leave the allocation
+  const size_t pad = static_cast<size_t>(FILTER_ROWS) * dim * bpe_of(dtype) + 4096;   // zero rows up to a whole 32-row tile (+ slack for vector loads)
+  HIPCHK(c, hipMalloc(&c->rows, bytes + pad));
+  HIPCHK(c, hipMemset(static_cast<char*>(c->rows) + bytes, 0, pad));
   c->owned = true;
   const size_t chunk = size_t(256) << 20;
   for (size_t off = 0; off < bytes; off += chunk) {
@@ -480,7 +525,8 @@ nvdb_status nvdb_hip_upload_corpus(nvdb_hip_ctx* c, const void* rows, const floa
     HIPCHK(c, hipMemcpy(static_cast<char*>(c->rows) + off, static_cast<const char*>(rows) + off, take, hipMemcpyHostToDevice));
   }
   if (dtype == NVDB_DTYPE_I8) {
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), n * sizeof(float)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), (n + FILTER_ROWS) * sizeof(float)));
+    HIPCHK(c, hipMemset(c->scales + n, 0, FILTER_ROWS * sizeof(float)));
     HIPCHK(c, hipMemcpy(c->scales, scales, n * sizeof(float), hipMemcpyHostToDevice));
   }
   c->n = n; c->dim = dim; c->dtype = dtype; c->row_base = global_row_base;
@@ -507,9 +553,14 @@ nvdb_status nvdb_hip_generate_corpus(nvdb_hip_ctx* c, uint64_t seed, uint64_t n,
   HIPCHK(c, hipSetDevice(c->device));
   free_corpus(c);
   const size_t bytes = static_cast<size_t>(n) * dim * bpe_of(dtype);
-  HIPCHK(c, hipMalloc(&c->rows, bytes + 4096));
+  const size_t pad = static_cast<size_t>(FILTER_ROWS) * dim * bpe_of(dtype) + 4096;
+  HIPCHK(c, hipMalloc(&c->rows, bytes + pad));
+  HIPCHK(c, hipMemset(static_cast<char*>(c->rows) + bytes, 0, pad));
   c->owned = true;
-  if (dtype == NVDB_DTYPE_I8) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), n * sizeof(float)));
+  if (dtype == NVDB_DTYPE_I8) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), (n + FILTER_ROWS) * sizeof(float)));
+    HIPCHK(c, hipMemset(c->scales + n, 0, FILTER_ROWS * sizeof(float)));
+  }
   c->n = n; c->dim = dim; c->dtype = dtype; c->row_base = global_row_base;
   // launch in slabs so that a single launch stays well inside the grid-size limit
   const uint64_t slab = 1ull << 24;
@@ -555,6 +606,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "cand_cap") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "cand_cap out of range"); c->opt_cap = value; }
   else if (k == "time_kernels") { c->opt_time_kernels = value ? 1 : 0; }
   else if (k == "mfma16") { c->opt_mfma16 = value ? 1 : 0; }
+  else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
   else if (k == "refine_v2") { c->opt_refine_v2 = value ? 1 : 0; }
   else if (k == "chunk_growth") { if (value < 2 || value > 64) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be in [2,64]"); c->opt_growth = value; }
   else if (k == "min_filter_batch") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "min_filter_batch must be >= 1"); c->opt_min_filter_batch = value; }
@@ -710,7 +762,7 @@ nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* c, int variant, uint32_t
       if (r == 1) HIPCHK(c, hipEventRecord(e0, c->stream));                                                                    \
       filter_f16_kernel<768, 2, V, RG><<<nwg, 256, lds, c->stream>>>(static_cast<const _Float16*>(c->rows), 0, n_al, static_cast<const _Float16*>(c->q16.p), nq, QT, \
           static_cast<const float*>(inf.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),     \
-          static_cast<uint32_t*>(c->hitcnt.p));                                                                                \
+          static_cast<uint32_t*>(c->hitcnt.p), 0u);                                                                            \
     }                                                                                                                          \
   }
   switch (variant) {
