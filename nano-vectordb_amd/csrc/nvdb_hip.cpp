@@ -405,7 +405,9 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t n_al = c->owned ? (n + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS : n / FILTER_ROWS * FILTER_ROWS;
   uint32_t r = 0;
   uint64_t size;
-  const uint32_t boot_rows = 2048;
+  // T tile maxima with T >= 8k: their k-th largest is then close to the k-th best of the 32*T rows (with T == k it
+  // would be the smallest tile maximum, a uselessly weak threshold)
+  const uint32_t boot_rows = FILTER_ROWS * std::max<uint32_t>(64u, 8u * k_eff);
   const bool mfma_boot = c->dtype == NVDB_DTYPE_F16 && c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
                          boot_rows / FILTER_ROWS <= cap;
   if (mfma_boot) {
