@@ -339,3 +339,59 @@ def test_refine_argument_conventions(ctx, oracle):
     ctx.upload_corpus(b8, po.DT_I8, sc)
     with pytest.raises(nvdb_amd.NvdbError):
         ctx.refine_l2_topk(q, np.zeros((2, 4), dtype=np.uint32), 3)              # int8 base unsupported (nvdb_ivf_eval.cpp:519-525)
+
+
+# ----------------------------------------------------------------------------- BASELINE full sizes: size-independent properties
+@pytest.mark.parametrize("dtype,tag", [(nvdb_amd.DT_F16, "f16"), (nvdb_amd.DT_I8, "i8")])
+def test_full_size_10M_properties(oracle, dtype, tag):
+    """N = 10M, d = 768, B = 1024, k = 10 (BASELINE configs[1] / [2]).  The oracle cannot scan 10M x 1024 in
+    seconds, so parity is checked through properties that do not depend on size:
+      (a) every returned score is, bit for bit, the reference CPU score of the returned row (oracle dot on
+          rows copied back from HBM) and lists are in canonical (score desc, id asc) order;
+      (b) no row of a 200K-row sample beats a query's k-th score (oracle scan of the sample);
+      (c) sharding: top-k of [0,6M) merged with top-k of [6M,10M) == top-k of [0,10M);
+      (d) idempotence, and the MFMA path == the exact fp32 kernel on a subset of the batch."""
+    n, d, nq, k = 10_000_000, 768, 1024, 10
+    dt_o = po.DT_F16 if dtype == nvdb_amd.DT_F16 else po.DT_I8
+    ctx = nvdb_amd.HipContext(0)
+    ctx.generate_corpus(SEED, n, d, dtype)
+    queries = nvdb_amd.synth_rows_f32(SEED + 1, 0, nq, d)
+    ids, sc = ctx.search_batch(queries, k)
+    st = ctx.stats()
+    assert st["path"] == 2 and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    assert ids.shape == (nq, k)
+    # (a)
+    for qi in range(0, nq, 97):
+        for j in range(k):
+            row, rsc = ctx.download_rows(int(ids[qi, j]), 1)
+            if dtype == nvdb_amd.DT_F16:
+                s = oracle.lib.oracle_dot_f32_f16base(po._p(queries[qi], po._f32p), row.ctypes.data, d)
+            else:
+                s = oracle.lib.oracle_dot_f32_i8base(po._p(queries[qi], po._f32p), row.ctypes.data, d, float(rsc[0]))
+            assert np.float32(s).view(np.uint32) == sc[qi, j].view(np.uint32), (qi, j)
+    assert np.all((sc[:, :-1] > sc[:, 1:]) | ((sc[:, :-1] == sc[:, 1:]) & (ids[:, :-1] < ids[:, 1:])))
+    assert all(len(set(r.tolist())) == k for r in ids)
+    # (b)
+    lo = 4_321_000
+    sample, ssc = ctx.download_rows(lo, 200_000)
+    for qi in (0, 511, 1023):
+        allsc = oracle.scores(sample, dt_o, queries[qi], ssc)
+        better = np.flatnonzero(allsc > sc[qi, -1]) + lo
+        assert set(better.tolist()) <= set(ids[qi].tolist()), qi
+    # (d) idempotence + exact kernel on a subset
+    ids2, sc2 = ctx.search_batch(queries, k)
+    assert np.array_equal(ids, ids2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+    ctx.set_option("path", 1)
+    ide, sce = ctx.search_batch(queries[:8], k)
+    ctx.set_option("path", 0)
+    assert np.array_equal(ide, ids[:8]) and np.array_equal(sce.view(np.uint32), sc[:8].view(np.uint32))
+    ctx.close()
+    # (c)
+    parts = []
+    for lo_, hi_ in ((0, 6_000_000), (6_000_000, n)):
+        c = nvdb_amd.HipContext(0)
+        c.generate_corpus(SEED, hi_ - lo_, d, dtype, row_base=lo_)
+        parts.append(c.search_batch(queries, k))
+        c.close()
+    mi, ms = nvdb_amd.merge_topk_host(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+    assert np.array_equal(mi, ids) and np.array_equal(ms.view(np.uint32), sc.view(np.uint32))
