@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-sample-queries", type=int, default=96)
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 exact kernel, 2 MFMA filter")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (nvdb_hip_set_option), repeatable")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (HBM-bound point, int8, refine)")
     ap.add_argument("--verify-merge", action="store_true", help="N>1: rank 0 also searches the unsharded corpus and compares the merged lists")
     ap.add_argument("--sweep", default="", help="comma list of extra batch sizes to time (N=1 only), e.g. 1,16,64,256")
     return ap.parse_args()
@@ -306,6 +307,67 @@ def main():
                           "tflops": 2.0 * b * N * D / (el / reps) / 1e12,
                           "filter_kernel_ms_per_pass": (k2["ms"] / reps) if k2["launches"] else None})
         out["sweep"] = sweep
+
+    # ---- secondary measurements (N=1 only; the headline `value` above is unaffected) ------------------------
+    if rank == 0 and world == 1 and not args.no_extras and args.dtype == "f16":
+        extras = {}
+        try:
+            def timed_passes(c, qd, b, reps=6):
+                oi = torch.empty((b, K), dtype=torch.int64, device=dev)
+                os_ = torch.empty((b, K), dtype=torch.float32, device=dev)
+                strm = torch.cuda.current_stream().cuda_stream
+                for _ in range(2):
+                    c.search_batch_dev(qd.data_ptr(), b, K, oi.data_ptr(), os_.data_ptr(), strm)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    c.search_batch_dev(qd.data_ptr(), b, K, oi.data_ptr(), os_.data_ptr(), strm)
+                torch.cuda.synchronize()
+                el = (time.perf_counter() - t0) / reps
+                c.search_check()
+                return el
+            # (1) HBM-bound point of the same fp16 corpus: batch 64
+            el = timed_passes(ctx, qdev, 64)
+            extras["fp16_batch64"] = {"workload": f"fp16 flat-scan top-{K}, N={N} d={D}, batch=64", "qps": 64 / el, "ms_per_pass": el * 1e3,
+                                      "hbm_GBps": N * D * 2 / 1e9 / el, "hbm_frac": N * D * 2 / 1e9 / el / PEAK_HBM_GBPS}
+            # (2) BASELINE configs[2]: int8(+scale), same shape
+            c8 = nvdb_amd.HipContext(local_rank)
+            c8.generate_corpus(SEED, N, D, nvdb_amd.DT_I8)
+            for bb in (B, 64):
+                el = timed_passes(c8, qdev, bb)
+                extras[f"int8_batch{bb}"] = {"workload": f"int8+scale flat-scan top-{K}, N={N} d={D}, batch={bb}", "qps": bb / el, "ms_per_pass": el * 1e3,
+                                             "hbm_GBps": N * (D + 4) / 1e9 / el, "hbm_frac": N * (D + 4) / 1e9 / el / PEAK_HBM_GBPS}
+            # recall@10 of the int8 corpus against the fp32 corpus' exact top-10 (500K-row prefix, 64 queries)
+            nr = min(N, 500_000)
+            c32 = nvdb_amd.HipContext(local_rank)
+            c32.generate_corpus(SEED, nr, D, nvdb_amd.DT_F32)
+            g_ids, _ = c32.search_batch(qhost[:64], K)
+            c32.close()
+            c8s = nvdb_amd.HipContext(local_rank)
+            c8s.generate_corpus(SEED, nr, D, nvdb_amd.DT_I8)
+            i_ids, _ = c8s.search_batch(qhost[:64], K)
+            c8s.close()
+            extras["int8_recall_at_10_vs_fp32"] = float(np.mean([len(set(a.tolist()) & set(b_.tolist())) / K for a, b_ in zip(g_ids, i_ids)]))
+            c8.close()
+            # (3) BASELINE configs[4]: exact-L2 refine, N=2.9M fp16, Q=10000, R=1024, K=10, synthetic candidates
+            NR, QR, RR = min(N, 2_900_000), 10_000, 1024
+            cr = nvdb_amd.HipContext(local_rank)
+            cr.generate_corpus(SEED, NR, D, nvdb_amd.DT_F16)
+            rq = nvdb_amd.synth_rows_f32(SEED + 2, 0, QR, D)
+            rs_ = np.random.RandomState(1)
+            cand = rs_.randint(0, NR, size=(QR, RR)).astype(np.uint32)
+            cand[rs_.rand(QR, RR) < 0.01] = 0xFFFFFFFF
+            best = None
+            for _ in range(3):
+                _, _, t = cr.refine_l2_topk(rq, cand, K, want_timing=True)
+                best = t.kernel_ms if best is None else min(best, t.kernel_ms)
+            cr.close()
+            gb = QR * RR * 0.99 * D * 2 / 1e9
+            extras["refine"] = {"workload": f"exact-L2 refine N={NR} Q={QR} R={RR} K={K} fp16", "kernel_ms": best, "us_per_query": best * 1e3 / QR,
+                                "h2d_ms": t.h2d_ms, "d2h_ms": t.d2h_ms, "gather_GBps": gb / (best * 1e-3), "hbm_frac": gb / (best * 1e-3) / PEAK_HBM_GBPS}
+        except Exception as e:
+            extras["error"] = repr(e)
+        out["extras"] = extras
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
