@@ -44,7 +44,7 @@ constexpr int FILTER_STAGES = 3;
 // grid = nq_pad (multiple of 256), block = 256.  Pad queries get zeros.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim,
-                                                       float max_row_norm, float rel, _Float16* __restrict__ q16,
+                                                       float max_row_norm, float rel, float abs_per_norm, _Float16* __restrict__ q16,
                                                        float* __restrict__ qscale, float* __restrict__ qinv,
                                                        float* __restrict__ ebound, float* __restrict__ slack) {
   __shared__ float red_max[4], red_ss[4];
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__
   for (uint32_t i = tid; i < dim; i += 256) q16[static_cast<uint64_t>(q) * dim + i] = static_cast<_Float16>(src[i] * sc);
   if (tid == 0) {
     const float nrm = sqrtf(ss) * 1.0001f;
-    const float eb = rel * nrm * max_row_norm + 1e-30f;
+    // abs_per_norm: absolute rounding of the corpus side (fp16 shadow of an fp32 corpus: subnormal halves)
+    const float eb = rel * nrm * max_row_norm + abs_per_norm * nrm + 1e-30f;
     qscale[q] = sc; qinv[q] = ldexpf(1.f, -e); ebound[q] = eb; slack[q] = 2.f * eb;
   }
 }
@@ -773,6 +774,20 @@ __global__ __launch_bounds__(256) void gen_rows_kernel(uint64_t seed, uint64_t r
     }
     if (lane == 0) scales[r] = scale;
   }
+}
+
+// fp32 corpus -> fp16 "shadow" copy for the MFMA filter (round-to-nearest-even) + max |x| (float bits via
+// atomicMax).  The fp32 rows stay the arbiter: every survivor is re-scored from them in the reference's order.
+__global__ __launch_bounds__(256) void shadow_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t count,
+                                                         uint32_t* __restrict__ maxabs_bits) {
+  float mx = 0.f;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<size_t>(gridDim.x) * 256) {
+    const float v = src[i];
+    dst[i] = static_cast<_Float16>(v);
+    mx = fmaxf(mx, fabsf(v));
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(maxabs_bits, __builtin_bit_cast(uint32_t, mx));
 }
 
 // max over rows of the (dequantised) L2 norm, slightly inflated; result as float bits via atomicMax

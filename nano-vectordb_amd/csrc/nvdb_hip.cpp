@@ -54,6 +54,7 @@ struct nvdb_hip_ctx {
   uint32_t dim = 0, dtype = 0;
   uint64_t row_base = 0;
   float max_norm = 0.f;
+  _Float16* shadow16 = nullptr;                    // fp32 corpus only: fp16 copy streamed by the MFMA filter
 
   // grow-only workspace
   DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, hitcnt;
@@ -73,6 +74,7 @@ struct nvdb_hip_ctx {
   struct KLaunch { hipEvent_t e0, e1; double flops, bytes; };
   std::vector<KLaunch> klaunch;
   int64_t opt_time_kernels = 0;
+  int64_t opt_f32_shadow = 1;                      // 1: fp32 corpora get an fp16 shadow copy for the MFMA filter
   int64_t opt_mfma_boot = 1;                       // 1: threshold bootstrap on the matrix cores (fp16 corpora)
   int64_t opt_refine_v2 = 1;                       // 1: LDS-staged coalesced gather in the refine kernel
   int64_t opt_mfma16 = 1;                          // 1: use the 16x16x32 MFMA build for 256-query tiles
@@ -129,6 +131,7 @@ void free_corpus(nvdb_hip_ctx* c) {
     if (c->rows) (void)hipFree(c->rows);
     if (c->scales) (void)hipFree(c->scales);
   }
+  if (c->shadow16) { (void)hipFree(c->shadow16); c->shadow16 = nullptr; }
   c->rows = nullptr; c->scales = nullptr; c->owned = false; c->n = 0; c->dim = 0; c->dtype = 0; c->max_norm = 0.f;
 }
 
@@ -146,6 +149,20 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   HIPCHK(c, hipMemcpyAsync(&h, bits, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memcpy(&c->max_norm, &h, 4);
+  // fp32 corpus with a filter-capable dim: fp16 shadow copy (skipped when values would overflow a half)
+  if (c->dtype == NVDB_DTYPE_F32 && (c->dim == 768 || c->dim == 384) && c->opt_f32_shadow) {
+    const size_t count = static_cast<size_t>(c->n) * c->dim;
+    const size_t pad = static_cast<size_t>(FILTER_ROWS) * c->dim * 2 + 4096;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow16), count * 2 + pad));
+    HIPCHK(c, hipMemsetAsync(reinterpret_cast<char*>(c->shadow16) + count * 2, 0, pad, c->stream));
+    HIPCHK(c, hipMemsetAsync(bits, 0, 4, c->stream));
+    shadow_f16_kernel<<<4096, 256, 0, c->stream>>>(static_cast<const float*>(c->rows), c->shadow16, count, bits);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&h, bits, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float maxabs; std::memcpy(&maxabs, &h, 4);
+    if (!(maxabs < 60000.f)) { (void)hipFree(c->shadow16); c->shadow16 = nullptr; }
+  }
   return NVDB_OK;
 }
 
@@ -230,8 +247,14 @@ nvdb_status launch_rescore(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uin
   return NVDB_OK;
 }
 
+// what the fp16 MFMA kernels stream: the corpus itself, or the fp16 shadow of an fp32 corpus
+const _Float16* filter_rows_f16(const nvdb_hip_ctx* c) {
+  return c->dtype == NVDB_DTYPE_F32 ? c->shadow16 : static_cast<const _Float16*>(c->rows);
+}
+
 bool filter_supported(const nvdb_hip_ctx* c) {
   if (c->dtype == NVDB_DTYPE_F16) return c->dim == 768 || c->dim == 384;
+  if (c->dtype == NVDB_DTYPE_F32) return c->shadow16 != nullptr;
   if (c->dtype == NVDB_DTYPE_I8) return c->dim == 768 || c->dim == 512 || c->dim == 256;   // int8 rows: stride % 256 == 0
   return false;
 }
@@ -252,12 +275,12 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
   if ((st = ensure(c, c->hitcnt, static_cast<size_t>(nwg) * 4 * 4))) return st;
   if (m16)
-    filter_f16_m16_kernel<DIM><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), row_lo, row_hi,
+    filter_f16_m16_kernel<DIM><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
                                                      static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                      static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
                                                      static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p));
   else
-    filter_f16_kernel<DIM, NB><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), row_lo, row_hi,
+    filter_f16_kernel<DIM, NB><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
                                                      static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                      static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
                                                      static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p), 0u);
@@ -309,7 +332,7 @@ nvdb_status launch_boot_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_
   }
   uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
   if (nwg == 0) nwg = QT;
-  filter_f16_kernel<DIM, NB, 7><<<nwg, 256, lds, s>>>(static_cast<const _Float16*>(c->rows), 0, n0, static_cast<const _Float16*>(c->q16.p), nq, QT,
+  filter_f16_kernel<DIM, NB, 7><<<nwg, 256, lds, s>>>(filter_rows_f16(c), 0, n0, static_cast<const _Float16*>(c->q16.p), nq, QT,
                                                       static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                       static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->cand.p),
                                                       static_cast<uint32_t*>(c->hitcnt.p), cap);
@@ -352,7 +375,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t n = static_cast<uint32_t>(c->n);
   int path = force_path ? force_path : static_cast<int>(c->opt_path);
   if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
-  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16 corpus with dim 768/384 or an int8 corpus with dim 768/512/256");
+  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim 768/384 or an int8 corpus with dim 768/512/256");
 
   uint32_t cap = c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : (nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
@@ -395,20 +418,23 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
                                           static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
                                           static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
   else
-    prep_q16_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->max_norm, FILTER_REL_F16, static_cast<_Float16*>(c->q16.p),
+    // fp32 corpus: the shadow adds 2^-11 relative (normal halves) and <= 2^-25 absolute per element (subnormal halves)
+    prep_q16_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->max_norm, c->dtype == NVDB_DTYPE_F32 ? FILTER_REL_F16 + 4.9e-4f : FILTER_REL_F16,
+                                           c->dtype == NVDB_DTYPE_F32 ? 3.0e-8f * std::sqrt(static_cast<float>(c->dim)) : 0.f, static_cast<_Float16*>(c->q16.p),
                                            static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
                                            static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
   HIPCHK(c, hipGetLastError());
   const float* slack = static_cast<const float*>(c->slack.p);
   // Whole tiles: a corpus this library allocated is zero-padded to a multiple of 32 rows (the padded rows are
   // dropped by scatter_hits_kernel); for an adopted corpus the ragged tail goes to the exact kernel.
-  const uint32_t n_al = c->owned ? (n + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS : n / FILTER_ROWS * FILTER_ROWS;
+  const bool padded = c->owned || c->dtype == NVDB_DTYPE_F32;      // the fp16 shadow is always ours, hence padded
+  const uint32_t n_al = padded ? (n + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS : n / FILTER_ROWS * FILTER_ROWS;
   uint32_t r = 0;
   uint64_t size;
   // T tile maxima with T >= 8k: their k-th largest is then close to the k-th best of the 32*T rows (with T == k it
   // would be the smallest tile maximum, a uselessly weak threshold)
   const uint32_t boot_rows = FILTER_ROWS * std::max<uint32_t>(64u, 8u * k_eff);
-  const bool mfma_boot = c->dtype == NVDB_DTYPE_F16 && c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
+  const bool mfma_boot = c->dtype != NVDB_DTYPE_I8 && c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
                          boot_rows / FILTER_ROWS <= cap;
   if (mfma_boot) {
     // thresholds from the k-th largest of the 64 tile maxima of rows [0,2048); those rows are then scanned
@@ -433,7 +459,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     if (acct) {
       HIPCHK(c, hipEventCreate(&kl.e0)); HIPCHK(c, hipEventCreate(&kl.e1));
       kl.flops = 2.0 * nq * static_cast<double>(std::min(hi, n) - r) * c->dim;   // algorithmic: real queries, real rows
-      kl.bytes = static_cast<double>(std::min(hi, n) - r) * (c->dim * static_cast<double>(bpe_of(c->dtype)) + (c->dtype == NVDB_DTYPE_I8 ? 4.0 : 0.0));   // rows read once
+      kl.bytes = static_cast<double>(std::min(hi, n) - r) * (c->dim * (c->dtype == NVDB_DTYPE_F32 ? 2.0 : static_cast<double>(bpe_of(c->dtype))) + (c->dtype == NVDB_DTYPE_I8 ? 4.0 : 0.0));   // rows streamed once
       HIPCHK(c, hipEventRecord(kl.e0, s));
     }
     if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev), s)); }
@@ -608,6 +634,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "cand_cap") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "cand_cap out of range"); c->opt_cap = value; }
   else if (k == "time_kernels") { c->opt_time_kernels = value ? 1 : 0; }
   else if (k == "mfma16") { c->opt_mfma16 = value ? 1 : 0; }
+  else if (k == "f32_shadow") { c->opt_f32_shadow = value ? 1 : 0; }
   else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
   else if (k == "refine_v2") { c->opt_refine_v2 = value ? 1 : 0; }
   else if (k == "chunk_growth") { if (value < 2 || value > 64) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be in [2,64]"); c->opt_growth = value; }

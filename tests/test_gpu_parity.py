@@ -134,6 +134,29 @@ def test_filter_path_f16_matches_oracle(ctx, oracle, nq, k):
     _check_against_oracle(oracle, base, po.DT_F16, None, queries, ids, sc, k, f"filter/nq{nq}/k{k}")
 
 
+@pytest.mark.parametrize("nq", [5, 200])
+def test_filter_path_fp32_corpus_via_fp16_shadow(ctx, oracle, golden, nq):
+    """fp32 corpus: the MFMA filter streams an fp16 shadow copy, survivors are re-scored from the fp32 rows in
+    the reference's order (simd_dot.cpp:26-49) -> ids and score bits identical to the CPU path."""
+    n, d, k = 70000 + 3, 768, 10
+    ctx.generate_corpus(SEED + 60, n, d, nvdb_amd.DT_F32)
+    base, _ = nvdb_amd.synth_corpus(SEED + 60, 0, n, d, nvdb_amd.DT_F32)
+    queries = nvdb_amd.synth_rows_f32(SEED + 61, 0, nq, d)
+    queries[0] = base[12345]
+    ctx.set_option("path", 2)
+    ids, sc = ctx.search_batch(queries, k)
+    st = ctx.stats()
+    ctx.set_option("path", 0)
+    assert st["path"] == 2 and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    _check_against_oracle(oracle, base, po.DT_F32, None, queries, ids, sc, k, f"f32-shadow/nq{nq}")
+    # the reference's own golden case through the automatic path choice
+    base32, gq = make_case_inputs("main768")
+    ctx.upload_corpus(base32, po.DT_F32)
+    gi, gs = ctx.search_batch(gq, 10)
+    assert ctx.stats()["path"] == 2
+    assert np.array_equal(gi, golden["main768_f32_st_ids"]) and np.array_equal(gs.view(np.uint32), golden["main768_f32_st_scores"])
+
+
 def test_filter_path_mfma16_variant_matches_default(ctx, oracle):
     """The 16x16x32-MFMA build of the filter kernel must give the same bits as the 32x32x16 build."""
     n, d, nq, k = 90000 + 5, 768, 300, 10
