@@ -153,11 +153,13 @@ def main():
     nbatches = 4
     qhost = nvdb_amd.synth_rows_f32(SEED + 1, 0, nbatches * B, D)
     qdev = torch.from_numpy(qhost).to(dev).contiguous()
-    out_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
-    out_sc = torch.empty((B, K), dtype=torch.float32, device=dev)
+    # one packed result buffer per rank: [ids: B*K int64 | scores: B*K float32] -> ONE all-gather per step
+    PACK = B * K * 12
+    packed = torch.empty(PACK, dtype=torch.uint8, device=dev)
+    out_ids = packed[:B * K * 8].view(torch.int64).view(B, K)
+    out_sc = packed[B * K * 8:].view(torch.float32).view(B, K)
     if world > 1:
-        g_ids = torch.empty((world * B, K), dtype=torch.int64, device=dev)      # [W][B][K], concatenated along dim 0
-        g_sc = torch.empty((world * B, K), dtype=torch.float32, device=dev)
+        gathered = torch.empty(world * PACK, dtype=torch.uint8, device=dev)
         m_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
         m_sc = torch.empty((B, K), dtype=torch.float32, device=dev)
 
@@ -167,16 +169,13 @@ def main():
         ctx.search_batch_dev(q.data_ptr(), batch, K, out_ids.data_ptr(), out_sc.data_ptr(), stream)
         if world > 1:
             if share_gpu:
-                hi_, hs_ = out_ids.cpu(), out_sc.cpu()
-                ci, cs = torch.empty((world * B, K), dtype=torch.int64), torch.empty((world * B, K), dtype=torch.float32)
-                dist.all_gather_into_tensor(ci, hi_)
-                dist.all_gather_into_tensor(cs, hs_)
-                g_ids.copy_(ci)
-                g_sc.copy_(cs)
+                cg = torch.empty(world * PACK, dtype=torch.uint8)
+                dist.all_gather_into_tensor(cg, packed.cpu())
+                gathered.copy_(cg)
             else:
-                dist.all_gather_into_tensor(g_ids, out_ids)   # RCCL over xGMI: B*k*(8+4) bytes per rank
-                dist.all_gather_into_tensor(g_sc, out_sc)
-            ctx.merge_topk_dev(g_ids.data_ptr(), g_sc.data_ptr(), world, batch, K, m_ids.data_ptr(), m_sc.data_ptr(), stream)
+                dist.all_gather_into_tensor(gathered, packed)   # RCCL over xGMI: B*k*(8+4) = 123 KB per rank, one collective
+            ctx.merge_topk_strided_dev(gathered.data_ptr(), gathered.data_ptr() + B * K * 8, PACK, PACK, world, batch, K,
+                                       m_ids.data_ptr(), m_sc.data_ptr(), stream)
 
     def barrier():
         torch.cuda.synchronize()

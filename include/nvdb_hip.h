@@ -148,6 +148,12 @@ nvdb_status nvdb_hip_get_stats(nvdb_hip_ctx* ctx, nvdb_hip_scan_stats* stats);
 nvdb_status nvdb_hip_merge_topk_dev(nvdb_hip_ctx* ctx, const uint64_t* dev_ids, const float* dev_scores,
                                     uint32_t nshards, uint32_t nq, uint32_t k, uint64_t* dev_out_ids,
                                     float* dev_out_scores, void* hip_stream);
+/* Same with explicit byte strides between consecutive shards' blocks: lets each rank all-gather ONE packed buffer
+ * [ids (nq*k*8 bytes) | scores (nq*k*4 bytes)] and merge it in place (stride = nq*k*12 for both). */
+nvdb_status nvdb_hip_merge_topk_strided_dev(nvdb_hip_ctx* ctx, const uint64_t* dev_ids, const float* dev_scores,
+                                            size_t stride_ids_bytes, size_t stride_scores_bytes, uint32_t nshards,
+                                            uint32_t nq, uint32_t k, uint64_t* dev_out_ids, float* dev_out_scores,
+                                            void* hip_stream);
 /* Host version of the same merge (no GPU needed). */
 nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint32_t nshards, uint32_t nq,
                                  uint32_t k, uint64_t* out_ids, float* out_scores);

@@ -387,17 +387,20 @@ __global__ __launch_bounds__(256) void rescore_kernel(
 // merge of per-shard top-k lists: in[s][nq][k] -> out[nq][k]; rank-based (entries are unique).
 // grid = nq, block = 256; nshards*k <= 4096.
 // ------------------------------------------------------------------------------------------------
+// Shard s's ids start at ids + s*stride_ids_bytes, its scores at scores + s*stride_scores_bytes (so that one
+// all-gather of a packed [ids | scores] buffer per rank can be merged in place).
 __global__ __launch_bounds__(256) void merge_topk_kernel(
     const unsigned long long* __restrict__ ids, const float* __restrict__ scores, uint32_t nshards, uint32_t nq,
-    uint32_t k, unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores) {
+    uint32_t k, unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, size_t stride_ids_bytes,
+    size_t stride_scores_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const uint32_t m = nshards * k, q = blockIdx.x;
   float* s = reinterpret_cast<float*>(smem_raw);
   unsigned long long* id = reinterpret_cast<unsigned long long*>(smem_raw + ((m * 4 + 15) & ~15u));
   for (uint32_t i = threadIdx.x; i < m; i += 256) {
     const uint32_t sh = i / k, j = i % k;
-    s[i] = scores[(static_cast<uint64_t>(sh) * nq + q) * k + j];
-    id[i] = ids[(static_cast<uint64_t>(sh) * nq + q) * k + j];
+    s[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(scores) + sh * stride_scores_bytes)[static_cast<uint64_t>(q) * k + j];
+    id[i] = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(ids) + sh * stride_ids_bytes)[static_cast<uint64_t>(q) * k + j];
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < m; i += 256) {

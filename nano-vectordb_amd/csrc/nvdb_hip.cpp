@@ -825,8 +825,9 @@ nvdb_status nvdb_hip_get_stats(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   return NVDB_OK;
 }
 
-nvdb_status nvdb_hip_merge_topk_dev(nvdb_hip_ctx* c, const uint64_t* dev_ids, const float* dev_scores, uint32_t nshards,
-                                    uint32_t nq, uint32_t k, uint64_t* dev_out_ids, float* dev_out_scores, void* hip_stream) {
+nvdb_status nvdb_hip_merge_topk_strided_dev(nvdb_hip_ctx* c, const uint64_t* dev_ids, const float* dev_scores, size_t stride_ids_bytes,
+                                            size_t stride_scores_bytes, uint32_t nshards, uint32_t nq, uint32_t k, uint64_t* dev_out_ids,
+                                            float* dev_out_scores, void* hip_stream) {
   if (!c) return NVDB_ERR_INVALID;
   if (!dev_ids || !dev_scores || !dev_out_ids || !dev_out_scores) return fail(c, NVDB_ERR_INVALID, "merge_topk: null pointer");
   if (nshards == 0 || nq == 0 || k == 0) return NVDB_OK;
@@ -836,9 +837,16 @@ nvdb_status nvdb_hip_merge_topk_dev(nvdb_hip_ctx* c, const uint64_t* dev_ids, co
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
   const size_t lds = ((m * 4 + 15) & ~15u) + static_cast<size_t>(m) * 8;
   merge_topk_kernel<<<nq, 256, lds, s>>>(reinterpret_cast<const unsigned long long*>(dev_ids), dev_scores, nshards, nq, k,
-                                         reinterpret_cast<unsigned long long*>(dev_out_ids), dev_out_scores);
+                                         reinterpret_cast<unsigned long long*>(dev_out_ids), dev_out_scores, stride_ids_bytes,
+                                         stride_scores_bytes);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_merge_topk_dev(nvdb_hip_ctx* c, const uint64_t* dev_ids, const float* dev_scores, uint32_t nshards,
+                                    uint32_t nq, uint32_t k, uint64_t* dev_out_ids, float* dev_out_scores, void* hip_stream) {
+  return nvdb_hip_merge_topk_strided_dev(c, dev_ids, dev_scores, static_cast<size_t>(nq) * k * 8, static_cast<size_t>(nq) * k * 4, nshards, nq,
+                                         k, dev_out_ids, dev_out_scores, hip_stream);
 }
 
 nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint32_t nshards, uint32_t nq, uint32_t k,
