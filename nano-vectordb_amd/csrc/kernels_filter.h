@@ -596,12 +596,14 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
 #define NVDB_MFMA_I8_ZERO(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b))
 #define NVDB_MFMA_I8_ACC(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 
-template <int DIM, int RING = 6>
+// BOOT = true: bootstrap build (see filter_f16_kernel VAR 7): best (score,row) per tile and query -> cand lists
+// (hitlog then points at the candidate lists, aux is their stride).
+template <int DIM, bool BOOT = false, int RING = 6>
 __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
     const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
     const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qinv,
-    Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt) {
+    Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt, uint32_t aux) {
   constexpr int KSTEPS = DIM / 32;                 // v_mfma_i32_32x32x32_i8: K = 32
   constexpr int ROW_BYTES = DIM;
   constexpr int DATA_BYTES = FILTER_ROWS * ROW_BYTES;
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
   const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
   const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
   const uint32_t NT = t_hi - t_lo;
-  if (NT == 0) { if (lane == 0) hitcnt[wave_gid] = 0; return; }
+  if (NT == 0) { if (!BOOT && lane == 0) hitcnt[wave_gid] = 0; return; }
 
   // stationary operand: 32 queries x two int8 planes x all of K, in AGPRs.  Lane (r31,hsel) holds bytes
   // [32 s + 16 hsel, +16) of its query -- the same k-slice the A fragment holds.
@@ -721,6 +723,20 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
         any |= fv[r] >= thr_s;
       }
     }
+    if constexpr (BOOT) {
+      const uint32_t tile = t_lo + t;
+      const uint32_t row0b = row_lo + tile * FILTER_ROWS;
+      float best = fv[0];
+      uint32_t brow = 0;
+#pragma unroll
+      for (int r = 1; r < 16; ++r) { const bool gt = fv[r] > best; best = gt ? fv[r] : best; brow = gt ? static_cast<uint32_t>(r) : brow; }
+      uint32_t grow = row0b + (brow & 3) + 8 * (brow >> 2) + 4 * hsel;
+      const float obest = __shfl_xor(best, 32);
+      const uint32_t orow = static_cast<uint32_t>(__shfl_xor(static_cast<int>(grow), 32));
+      if (obest > best || (obest == best && orow < grow)) { best = obest; grow = orow; }
+      if (hsel == 0 && qid < nq) reinterpret_cast<Cand*>(hitlog)[static_cast<uint64_t>(qid) * aux + tile] = Cand{best * inv_s, grow};
+      continue;
+    }
     if (__builtin_amdgcn_ballot_w64(any)) {
       const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
 #pragma unroll
@@ -735,7 +751,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
       }
     }
   }
-  if (lane == 0) hitcnt[wave_gid] = wcnt;
+  if (!BOOT && lane == 0) hitcnt[wave_gid] = wcnt;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

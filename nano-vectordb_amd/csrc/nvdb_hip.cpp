@@ -311,7 +311,7 @@ nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
   filter_i8_kernel<DIM><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
                                               static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                               static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
-                                              static_cast<uint32_t*>(c->hitcnt.p));
+                                              static_cast<uint32_t*>(c->hitcnt.p), 0u);
   HIPCHK(c, hipGetLastError());
   scatter_hits_kernel<<<nwg * 4, 64, 0, s>>>(static_cast<const Hit*>(c->hitlog.p), static_cast<const uint32_t*>(c->hitcnt.p),
                                              static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap,
@@ -340,7 +340,33 @@ nvdb_status launch_boot_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_
   return NVDB_OK;
 }
 
+template <int DIM>
+nvdb_status launch_boot_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap) {
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * (FILTER_ROWS * DIM + 4 * 1024);
+  const void* fn = reinterpret_cast<const void*>(filter_i8_kernel<DIM, true>);
+  if (!c->lds_attr_set.count(fn)) {
+    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    c->lds_attr_set.insert(fn);
+  }
+  uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
+  if (nwg == 0) nwg = QT;
+  const signed char* qhi = static_cast<const signed char*>(c->q16.p);
+  const signed char* qlo = qhi + static_cast<size_t>(QT) * 128u * DIM;
+  filter_i8_kernel<DIM, true><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, 0, n0, qhi, qlo, nq, QT,
+                                                    static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
+                                                    static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->cand.p),
+                                                    static_cast<uint32_t*>(c->hitcnt.p), cap);
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
 nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap, uint32_t nb) {
+  if (c->dtype == NVDB_DTYPE_I8) {
+    if (c->dim == 768) return launch_boot_i8_dim<768>(c, s, n0, nq, QT, cap);
+    if (c->dim == 512) return launch_boot_i8_dim<512>(c, s, n0, nq, QT, cap);
+    if (c->dim == 256) return launch_boot_i8_dim<256>(c, s, n0, nq, QT, cap);
+    return fail(c, NVDB_ERR_UNSUPPORTED, "int8 boot kernel: unsupported dim");
+  }
   if (c->dim == 768) return nb == 1 ? launch_boot_dim<768, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<768, 2>(c, s, n0, nq, QT, cap);
   if (c->dim == 384) return nb == 1 ? launch_boot_dim<384, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<384, 2>(c, s, n0, nq, QT, cap);
   return fail(c, NVDB_ERR_UNSUPPORTED, "boot kernel: unsupported dim");
@@ -434,7 +460,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // T tile maxima with T >= 8k: their k-th largest is then close to the k-th best of the 32*T rows (with T == k it
   // would be the smallest tile maximum, a uselessly weak threshold)
   const uint32_t boot_rows = FILTER_ROWS * std::max<uint32_t>(64u, 8u * k_eff);
-  const bool mfma_boot = c->dtype != NVDB_DTYPE_I8 && c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
+  const bool mfma_boot = c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
                          boot_rows / FILTER_ROWS <= cap;
   if (mfma_boot) {
     // thresholds from the k-th largest of the 64 tile maxima of rows [0,2048); those rows are then scanned
