@@ -368,11 +368,18 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
 #define NVDB_MFMA16_ACC_A(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 #define NVDB_MFMA16_ACC_V(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 
-template <int DIM, int RING = 6>
+// SYNC: the QT workgroups that stream the same rows (different query tiles, same XCD label) keep within
+// SYNC_LEAD tiles of each other, so that the XCD's L2 serves QT-1 of the QT reads of every tile.  Speed
+// only: a leader that does not see its siblings advance (other XCD, not resident) gives up after a bounded
+// spin; nothing is ever read through this channel except the progress counters themselves.
+constexpr uint32_t SYNC_MAX_SPINS = 400;
+
+template <int DIM, int RING = 6, bool SYNC = false>
 __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
     uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
-    const float* __restrict__ qinv, Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt) {
+    const float* __restrict__ qinv, Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt, uint32_t* __restrict__ prog,
+    uint32_t sync_mask, uint32_t sync_lead) {
   constexpr int KS = DIM / 32;                     // k-steps of 32
   constexpr int ROW_BYTES = DIM * 2;
   constexpr int STAGE_BYTES = FILTER_ROWS * ROW_BYTES;
@@ -453,8 +460,29 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   constexpr int PIECE_EVERY = NREAD / PPW;
   uint32_t wcnt = 0;
   Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
+  // progress counters of this stream's workgroups: prog[stream*8 + qt], 32-byte aligned group, unused slots 0xFFFFFFFF
+  uint32_t* myprog = prog + static_cast<uint64_t>(stream) * 8;
 
   for (uint32_t t = 0; t < NT; ++t) {
+    if constexpr (SYNC) {
+      if (wave == 0 && (t & sync_mask) == 0) {           // wave 0 only; the per-tile barrier holds the other waves back
+        if (lane == 0) __hip_atomic_store(myprog + qt, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t spin = 0; spin < SYNC_MAX_SPINS; ++spin) {
+          uint32_t p0, p1, p2, p3, p4, p5, p6, p7;
+          asm volatile("s_load_dwordx8 s[88:95], %8, 0x0 glc\n\ts_waitcnt lgkmcnt(0)\n\t"
+                       "s_mov_b32 %0, s88\n\ts_mov_b32 %1, s89\n\ts_mov_b32 %2, s90\n\ts_mov_b32 %3, s91\n\t"
+                       "s_mov_b32 %4, s92\n\ts_mov_b32 %5, s93\n\ts_mov_b32 %6, s94\n\ts_mov_b32 %7, s95"
+                       : "=s"(p0), "=s"(p1), "=s"(p2), "=s"(p3), "=s"(p4), "=s"(p5), "=s"(p6), "=s"(p7)
+                       : "s"(myprog)
+                       : "memory", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
+          uint32_t lo = p0 < p1 ? p0 : p1;
+          lo = lo < p2 ? lo : p2; lo = lo < p3 ? lo : p3; lo = lo < p4 ? lo : p4;
+          lo = lo < p5 ? lo : p5; lo = lo < p6 ? lo : p6; lo = lo < p7 ? lo : p7;
+          if (lo >= t || t - lo <= sync_lead) break;      // nobody is more than sync_lead tiles behind me
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+    }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     __builtin_amdgcn_s_barrier();
     const char* next_tile = tile_ptr(t + 2);
@@ -520,6 +548,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     }
   }
   if (lane == 0) hitcnt[wave_gid] = wcnt;
+  if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(myprog + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

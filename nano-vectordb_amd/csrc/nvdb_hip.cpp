@@ -57,7 +57,7 @@ struct nvdb_hip_ctx {
   _Float16* shadow16 = nullptr;                    // fp32 corpus only: fp16 copy streamed by the MFMA filter
 
   // grow-only workspace
-  DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, hitcnt;
+  DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, hitcnt, prog;
   DevBuf rq, rcand, rout_ids, rout_dist;           // refine
   void* pin = nullptr; size_t pin_bytes = 0;       // pinned staging
 
@@ -74,6 +74,8 @@ struct nvdb_hip_ctx {
   struct KLaunch { hipEvent_t e0, e1; double flops, bytes; };
   std::vector<KLaunch> klaunch;
   int64_t opt_time_kernels = 0;
+  int64_t opt_sync_every = 4, opt_sync_lead = 4;   // rendezvous period (power of two, tiles) and allowed lead
+  int64_t opt_sibling_sync = 1;                    // 1: co-streaming workgroups rendezvous every 8 tiles (L2 sharing)
   int64_t opt_f32_shadow = 1;                      // 1: fp32 corpora get an fp16 shadow copy for the MFMA filter
   int64_t opt_mfma_boot = 1;                       // 1: threshold bootstrap on the matrix cores (fp16 corpora)
   int64_t opt_refine_v2 = 1;                       // 1: LDS-staged coalesced gather in the refine kernel
@@ -274,11 +276,29 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
   nvdb_status st;
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
   if ((st = ensure(c, c->hitcnt, static_cast<size_t>(nwg) * 4 * 4))) return st;
-  if (m16)
-    filter_f16_m16_kernel<DIM><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
-                                                     static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
-                                                     static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
-                                                     static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p));
+  if (m16) {
+    const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8;
+    if (sync) {
+      if ((st = ensure(c, c->prog, static_cast<size_t>(nwg) * 8 * 4))) return st;
+      HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, static_cast<size_t>(nwg) * 8 * 4, s));       // unused / not-yet-started slots read as "far ahead"
+      const void* fs = reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM, 6, true>);
+      if (!c->lds_attr_set.count(fs)) {
+        HIPCHK(c, hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        c->lds_attr_set.insert(fs);
+      }
+      filter_f16_m16_kernel<DIM, 6, true><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
+                                                                static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
+                                                                static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
+                                                                static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p),
+                                                                static_cast<uint32_t*>(c->prog.p), static_cast<uint32_t>(c->opt_sync_every - 1),
+                                                                static_cast<uint32_t>(c->opt_sync_lead));
+    } else {
+      filter_f16_m16_kernel<DIM><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
+                                                       static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
+                                                       static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
+                                                       static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p), nullptr, 0u, 0u);
+    }
+  }
   else
     filter_f16_kernel<DIM, NB><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
                                                      static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
@@ -549,7 +569,7 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   free_corpus(c);
   for (DevBuf* b : {&c->q32, &c->q16, &c->qscale, &c->qinv, &c->ebound, &c->slack, &c->thr, &c->cnt, &c->overflow, &c->cand,
-                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->hitcnt, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
+                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->hitcnt, &c->prog, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
     if (b->p) (void)hipFree(b->p);
   if (c->pin) (void)hipHostFree(c->pin);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -660,6 +680,9 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "cand_cap") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "cand_cap out of range"); c->opt_cap = value; }
   else if (k == "time_kernels") { c->opt_time_kernels = value ? 1 : 0; }
   else if (k == "mfma16") { c->opt_mfma16 = value ? 1 : 0; }
+  else if (k == "sync_every") { if (value < 1 || (value & (value - 1))) return fail(c, NVDB_ERR_INVALID, "sync_every must be a power of two"); c->opt_sync_every = value; }
+  else if (k == "sync_lead") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "sync_lead must be >= 1"); c->opt_sync_lead = value; }
+  else if (k == "sibling_sync") { c->opt_sibling_sync = value ? 1 : 0; }
   else if (k == "f32_shadow") { c->opt_f32_shadow = value ? 1 : 0; }
   else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
   else if (k == "refine_v2") { c->opt_refine_v2 = value ? 1 : 0; }
