@@ -271,7 +271,15 @@ def main():
         gbps = kt["bytes"] / sec / 1e9
         # ridge point: intensity = 2*B*dim flop per row / row bytes  vs  peak flop / peak bytes
         hbm_bound = (2.0 * B * D / bpr) < (peak * 1e12 / (PEAK_HBM_GBPS * 1e9))
-        common = {"traffic": None, "kernel": kname, "launches": kt["launches"], "avg_launch_ms": kt["ms"] / kt["launches"],
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            ent = tj.get(f"{'fp16' if args.dtype == 'f16' else 'int8'} N={N} d={D} batch={B}")
+            if ent and world == 1:
+                traffic = ent["bytes_per_launch"]       # measured in a separate --pmc pass of this same command line
+        except Exception:
+            pass
+        common = {"traffic": traffic, "kernel": kname, "launches": kt["launches"], "avg_launch_ms": kt["ms"] / kt["launches"],
                   "kernel_time_share": kt["ms"] / (elapsed * 1e3), "mfma_T_per_s": ach, "mfma_frac": ach / peak,
                   "hbm_GBps_algorithmic": gbps, "hbm_frac": gbps / PEAK_HBM_GBPS}
         if hbm_bound:
