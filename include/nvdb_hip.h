@@ -169,6 +169,12 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* ctx, const char* key, int64_t valu
 nvdb_status nvdb_hip_collect_kernel_times(nvdb_hip_ctx* ctx, uint32_t* launches, double* total_ms,
                                           double* total_flops, double* total_bytes);
 
+/* Developer aid, not part of the drop-in surface: time ablation builds of the fp16 d=768 filter kernel (thresholds
+ * +inf, results discarded) on the resident corpus with the query workspace of the previous search (nq > 128).
+ * Variants: 0 normal, 1 no direct-to-LDS loads, 2 = 1 + no barrier, 3 no MFMA, 5 no LDS reads, 6-9 fragment ring
+ * 6/8/3/12, 10 L2-resident corpus. */
+nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* ctx, int variant, uint32_t nq, uint32_t reps, float* ms_per_launch);
+
 /* ---------------------------------------------------------------------------------------------
  * exact-L2 refine (rerank of R candidates per query) -- replaces nvdb::cuda_l2_topk_batch
  * (include/nvdb/cuda_refine.h:25-38, src/cuda_refine.cu:839-1173) on the resident corpus

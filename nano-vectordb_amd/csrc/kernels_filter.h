@@ -463,11 +463,13 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   // progress counters of this stream's workgroups: prog[stream*8 + qt], 32-byte aligned group, unused slots 0xFFFFFFFF
   uint32_t* myprog = prog + static_cast<uint64_t>(stream) * 8;
 
+  uint32_t sync_strikes = 0;                       // rendezvous that timed out; after 3 this workgroup stops waiting
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
       if (wave == 0 && (t & sync_mask) == 0) {           // wave 0 only; the per-tile barrier holds the other waves back
         if (lane == 0) __hip_atomic_store(myprog + qt, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t spin = 0; spin < SYNC_MAX_SPINS; ++spin) {
+        for (uint32_t spin = 0; sync_strikes < 3; ++spin) {
+          if (spin == SYNC_MAX_SPINS) { ++sync_strikes; break; }
           uint32_t p0, p1, p2, p3, p4, p5, p6, p7;
           asm volatile("s_load_dwordx8 s[88:95], %8, 0x0 glc\n\ts_waitcnt lgkmcnt(0)\n\t"
                        "s_mov_b32 %0, s88\n\ts_mov_b32 %1, s89\n\ts_mov_b32 %2, s90\n\ts_mov_b32 %3, s91\n\t"

@@ -59,7 +59,6 @@ struct nvdb_hip_ctx {
   // grow-only workspace
   DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, hitcnt, prog;
   DevBuf rq, rcand, rout_ids, rout_dist;           // refine
-  void* pin = nullptr; size_t pin_bytes = 0;       // pinned staging
 
   // options
   int64_t opt_path = 0, opt_chunk0 = 512, opt_cap = 0, opt_min_filter_batch = 1, opt_growth = 8;
@@ -108,14 +107,6 @@ nvdb_status ensure(nvdb_hip_ctx* c, DevBuf& b, size_t bytes) {
   return NVDB_OK;
 }
 
-nvdb_status ensure_pinned(nvdb_hip_ctx* c, size_t bytes) {
-  if (c->pin_bytes >= bytes) return NVDB_OK;
-  if (c->pin) { HIPCHK(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_bytes = 0; }
-  HIPCHK(c, hipHostMalloc(&c->pin, bytes, hipHostMallocDefault));
-  c->pin_bytes = bytes;
-  return NVDB_OK;
-}
-
 size_t bpe_of(uint32_t dtype) { return dtype == NVDB_DTYPE_F32 ? 4 : (dtype == NVDB_DTYPE_F16 ? 2 : (dtype == NVDB_DTYPE_I8 ? 1 : 0)); }
 
 bool aligned_rows(uint32_t dtype, uint32_t dim) {
@@ -152,7 +143,7 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memcpy(&c->max_norm, &h, 4);
   // fp32 corpus with a filter-capable dim: fp16 shadow copy (skipped when values would overflow a half)
-  if (c->dtype == NVDB_DTYPE_F32 && (c->dim == 768 || c->dim == 384) && c->opt_f32_shadow) {
+  if (c->dtype == NVDB_DTYPE_F32 && (c->dim == 768 || c->dim == 512 || c->dim == 384 || c->dim == 256 || c->dim == 128) && c->opt_f32_shadow) {
     const size_t count = static_cast<size_t>(c->n) * c->dim;
     const size_t pad = static_cast<size_t>(FILTER_ROWS) * c->dim * 2 + 4096;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow16), count * 2 + pad));
@@ -249,13 +240,16 @@ nvdb_status launch_rescore(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uin
   return NVDB_OK;
 }
 
+// dims the fp16 MFMA kernels are instantiated for (multiples of 128 up to 768: the 64 queries' fragments must fit 384 registers)
+bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128; }
+
 // what the fp16 MFMA kernels stream: the corpus itself, or the fp16 shadow of an fp32 corpus
 const _Float16* filter_rows_f16(const nvdb_hip_ctx* c) {
   return c->dtype == NVDB_DTYPE_F32 ? c->shadow16 : static_cast<const _Float16*>(c->rows);
 }
 
 bool filter_supported(const nvdb_hip_ctx* c) {
-  if (c->dtype == NVDB_DTYPE_F16) return c->dim == 768 || c->dim == 384;
+  if (c->dtype == NVDB_DTYPE_F16) return f16_filter_dim(c->dim);
   if (c->dtype == NVDB_DTYPE_F32) return c->shadow16 != nullptr;
   if (c->dtype == NVDB_DTYPE_I8) return c->dim == 768 || c->dim == 512 || c->dim == 256;   // int8 rows: stride % 256 == 0
   return false;
@@ -277,7 +271,8 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
   if ((st = ensure(c, c->hitcnt, static_cast<size_t>(nwg) * 4 * 4))) return st;
   if (m16) {
-    const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8;
+    // only when the kernel's XCD-aware mapping is active (the QT workgroups of a row stream share an XCD label)
+    const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
     if (sync) {
       if ((st = ensure(c, c->prog, static_cast<size_t>(nwg) * 8 * 4))) return st;
       HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, static_cast<size_t>(nwg) * 8 * 4, s));       // unused / not-yet-started slots read as "far ahead"
@@ -387,8 +382,9 @@ nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq
     if (c->dim == 256) return launch_boot_i8_dim<256>(c, s, n0, nq, QT, cap);
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 boot kernel: unsupported dim");
   }
-  if (c->dim == 768) return nb == 1 ? launch_boot_dim<768, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<768, 2>(c, s, n0, nq, QT, cap);
-  if (c->dim == 384) return nb == 1 ? launch_boot_dim<384, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<384, 2>(c, s, n0, nq, QT, cap);
+#define NVDB_BOOT_DIM(D) if (c->dim == D) return nb == 1 ? launch_boot_dim<D, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<D, 2>(c, s, n0, nq, QT, cap)
+  NVDB_BOOT_DIM(768); NVDB_BOOT_DIM(512); NVDB_BOOT_DIM(384); NVDB_BOOT_DIM(256); NVDB_BOOT_DIM(128);
+#undef NVDB_BOOT_DIM
   return fail(c, NVDB_ERR_UNSUPPORTED, "boot kernel: unsupported dim");
 }
 
@@ -404,8 +400,9 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
     if (c->dim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 filter kernel: unsupported dim");
   }
-  if (c->dim == 768) return nb == 1 ? launch_filter_dim<768, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<768, 2>(c, s, row_lo, row_hi, nq, QT, cap);
-  if (c->dim == 384) return nb == 1 ? launch_filter_dim<384, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<384, 2>(c, s, row_lo, row_hi, nq, QT, cap);
+#define NVDB_FILTER_DIM(D) if (c->dim == D) return nb == 1 ? launch_filter_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, cap)
+  NVDB_FILTER_DIM(768); NVDB_FILTER_DIM(512); NVDB_FILTER_DIM(384); NVDB_FILTER_DIM(256); NVDB_FILTER_DIM(128);
+#undef NVDB_FILTER_DIM
   return fail(c, NVDB_ERR_UNSUPPORTED, "filter kernel: unsupported dim");
 }
 
@@ -421,7 +418,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t n = static_cast<uint32_t>(c->n);
   int path = force_path ? force_path : static_cast<int>(c->opt_path);
   if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
-  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim 768/384 or an int8 corpus with dim 768/512/256");
+  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim 768/512/384/256/128 or an int8 corpus with dim 768/512/256");
 
   uint32_t cap = c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : (nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
@@ -571,7 +568,6 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
   for (DevBuf* b : {&c->q32, &c->q16, &c->qscale, &c->qinv, &c->ebound, &c->slack, &c->thr, &c->cnt, &c->overflow, &c->cand,
                     &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->hitcnt, &c->prog, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
     if (b->p) (void)hipFree(b->p);
-  if (c->pin) (void)hipHostFree(c->pin);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& k : c->klaunch) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
   (void)hipStreamDestroy(c->stream);

@@ -234,8 +234,9 @@ def test_filter_path_with_exact_duplicates(ctx, oracle):
     ctx.set_option("path", 0)
 
 
-def test_filter_and_exact_paths_agree_on_reference_dim_384(ctx, oracle):
-    n, d, nq, k = 80000, 384, 40, 10                         # the reference's own data dimension
+@pytest.mark.parametrize("d,nq", [(384, 40), (128, 200), (256, 33), (512, 150)])
+def test_filter_and_exact_paths_agree_on_other_dims(ctx, oracle, d, nq):
+    n, k = 80000, 10                                         # 384 is the reference's own data dimension
     ctx.generate_corpus(SEED + 2, n, d, nvdb_amd.DT_F16)
     base, _ = nvdb_amd.synth_corpus(SEED + 2, 0, n, d, nvdb_amd.DT_F16)
     queries = nvdb_amd.synth_rows_f32(SEED + 3, 0, nq, d)
@@ -246,7 +247,7 @@ def test_filter_and_exact_paths_agree_on_reference_dim_384(ctx, oracle):
         assert ctx.stats()["path"] == path
     ctx.set_option("path", 0)
     assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1].view(np.uint32), res[2][1].view(np.uint32))
-    _check_against_oracle(oracle, base, po.DT_F16, None, queries, res[2][0], res[2][1], k, "dim384")
+    _check_against_oracle(oracle, base, po.DT_F16, None, queries, res[2][0], res[2][1], k, f"dim{d}")
 
 
 def test_overflow_falls_back_to_exact_path(ctx, oracle):
