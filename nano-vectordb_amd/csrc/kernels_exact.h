@@ -310,9 +310,52 @@ __global__ __launch_bounds__(256) void select_kernel(
   const uint32_t q = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
   uint32_t m = cnt[q];
   if (m > cap) { if (tid == 0) overflow[q] = 1u; m = cap; }
+  Cand* mine = cand + static_cast<uint64_t>(q) * cap;
+  if (m <= 512) {
+    // short list (the usual case): rank every entry against all others with broadcast LDS reads -- one pass,
+    // two barriers, instead of the O(log^2 m) barrier stages of the bitonic network below.  Entries are
+    // distinct (a row occurs once per list), so ranks are a permutation = the sorted positions.
+    __shared__ float s_kth;
+    if (tid == 0) { s_keep = 0; s_kth = NEG_INF; }
+    for (uint32_t i = tid; i < m; i += nth) e[i] = mine[i];
+    __syncthreads();
+    Cand my[2];
+    uint32_t rk[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t i = tid + u * nth;
+      if (i < m) {
+        my[u] = e[i];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < m; ++j) { const Cand o = e[j]; r += better(o.score, o.row, my[u].score, my[u].row) ? 1u : 0u; }
+        rk[u] = r;
+        if (r == k - 1) s_kth = my[u].score;
+      }
+    }
+    __syncthreads();
+    if (mode == 1) {
+      const uint32_t c = m < k ? m : k;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (rk[u] < c) { out_ids[static_cast<uint64_t>(q) * out_k + rk[u]] = row_base + my[u].row; out_scores[static_cast<uint64_t>(q) * out_k + rk[u]] = my[u].score; }
+      for (uint32_t j = c + tid; j < out_k; j += nth) { out_ids[static_cast<uint64_t>(q) * out_k + j] = ~0ull; out_scores[static_cast<uint64_t>(q) * out_k + j] = NEG_INF; }
+      return;
+    }
+    const float sl = slack ? slack[q] : 0.f;
+    const float t = s_kth - sl;                   // s_kth stays -inf when m < k
+    uint32_t local = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (rk[u] != 0xFFFFFFFFu) local += (sl > 0.f ? (my[u].score >= t) : (rk[u] < k)) ? 1u : 0u;
+    if (local) atomicAdd(&s_keep, local);
+    __syncthreads();
+    const uint32_t keep = s_keep;                 // the kept entries are exactly ranks 0..keep-1
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (rk[u] < keep) mine[rk[u]] = my[u];
+    if (tid == 0) { cnt[q] = (mode == 2) ? 0u : keep; thr[q] = t; }
+    return;
+  }
   uint32_t M2 = 1;
   while (M2 < m) M2 <<= 1;
-  Cand* mine = cand + static_cast<uint64_t>(q) * cap;
   for (uint32_t i = tid; i < M2; i += nth) e[i] = (i < m) ? mine[i] : Cand{NEG_INF, 0xFFFFFFFFu};
   __syncthreads();
   for (uint32_t size = 2; size <= M2; size <<= 1) {
@@ -350,6 +393,14 @@ __global__ __launch_bounds__(256) void select_kernel(
   const uint32_t keep = s_keep;                          // sorted list -> the kept ones are a prefix
   for (uint32_t i = tid; i < keep; i += nth) mine[i] = e[i];
   if (tid == 0) { cnt[q] = (mode == 2) ? 0u : keep; thr[q] = t; }
+}
+
+// one launch that resets all per-search words: list lengths, overflow flags, thresholds (-inf), self-check words
+__global__ __launch_bounds__(256) void init_search_kernel(uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow,
+                                                          float* __restrict__ thr, uint32_t* __restrict__ misc, uint32_t nq_pad) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nq_pad) { cnt[i] = 0; overflow[i] = 0; thr[i] = NEG_INF; }
+  if (i < 4) misc[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -117,6 +117,35 @@ __device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_
 struct Hit { float score; uint32_t row; uint32_t qid; uint32_t pad; };
 constexpr uint32_t FILTER_LOGCAP = 512;            // entries per wave and launch
 
+// where the logged survivors go when the wave has finished its stream
+struct ScatterArgs {
+  Cand* cand;                // [nq][cap] candidate lists
+  uint32_t* cnt;             // [nq] list lengths (atomic slot allocation)
+  uint32_t* overflow;        // [nq] per-query list overflow flags
+  uint32_t* log_overflow;    // one word: some wave's log overflowed (unknown queries lost entries)
+  uint32_t cap;
+  uint32_t n_rows;           // rows >= n_rows are the zero rows that pad the corpus to whole tiles
+};
+
+// File this wave's logged survivors under their queries (cand[qid][slot], slot from an atomic counter).  Runs
+// once, after the tile loop: nothing is in flight any more, so the returning atomics cost nothing in the loop.
+__device__ __forceinline__ void scatter_own_log(const Hit* mylog, uint32_t wcnt, const ScatterArgs& a, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own log stores (and the speculative stages) have completed
+  uint32_t n = wcnt;
+  if (n > FILTER_LOGCAP) { if (lane == 0) *a.log_overflow = 1u; n = FILTER_LOGCAP; }
+  for (uint32_t i = lane; i < n; i += 64) {
+    // L2-served loads: the entries were written by this wave in this launch
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(mylog + i);
+    const uint32_t sbits = __hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t row = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t qid = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (row >= a.n_rows) continue;
+    const uint32_t slot = atomicAdd(&a.cnt[qid], 1u);
+    if (slot < a.cap) a.cand[static_cast<uint64_t>(qid) * a.cap + slot] = Cand{__builtin_bit_cast(float, sbits), row};
+    else a.overflow[qid] = 1u;
+  }
+}
+
 // VAR selects timing-only ablation builds (results are wrong for VAR != 0; used by
 // nvdb_hip_debug_filter_variant): 1 = no direct-to-LDS loads in the loop, 2 = 1 + no barrier,
 // 3 = no MFMA (loads + LDS reads only), 4 = no epilogue compare, 5 = no LDS reads (MFMA on a constant).
@@ -134,7 +163,7 @@ template <int DIM, int NB, int VAR = 0, int RING = 6>
 __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
     uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
-    const float* __restrict__ qinv, Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt, uint32_t aux) {
+    const float* __restrict__ qinv, Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t aux) {
   // aux: VAR 7 (bootstrap build) only -- hitlog then points at the candidate lists and aux is their stride
   constexpr int KSTEPS = DIM / 16;                 // MFMA k-steps per tile
   constexpr int ROW_BYTES = DIM * 2;
@@ -170,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
   const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
   const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
   const uint32_t NT = t_hi - t_lo;
-  if (NT == 0) { if (VAR != 7 && lane == 0) hitcnt[wave_gid] = 0; return; }
+  if (NT == 0) return;
 
   // ---- stationary operand: this wave's queries, all of K, in registers -------------------------
   // fragment f = nb*KSTEPS + s : query block nb (32 queries), k-step s.  Lane (r31,hsel) holds
@@ -353,8 +382,8 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
       }
     }
   }
-  if (VAR != 7 && lane == 0) hitcnt[wave_gid] = wcnt;   // > FILTER_LOGCAP means entries were dropped
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two speculative stages before exit
+  if constexpr (VAR == 0) scatter_own_log(mylog, wcnt, sa, lane);
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two speculative stages before exit
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,7 +407,7 @@ template <int DIM, int RING = 6, bool SYNC = false>
 __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
     uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
-    const float* __restrict__ qinv, Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt, uint32_t* __restrict__ prog,
+    const float* __restrict__ qinv, Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t* __restrict__ prog,
     uint32_t sync_mask, uint32_t sync_lead) {
   constexpr int KS = DIM / 32;                     // k-steps of 32
   constexpr int ROW_BYTES = DIM * 2;
@@ -403,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
   const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
   const uint32_t NT = t_hi - t_lo;
-  if (NT == 0) { if (lane == 0) hitcnt[wave_gid] = 0; return; }
+  if (NT == 0) return;
 
   // B fragment f = nb*KS + s: query block nb (16 queries), k-step s; lane (x15,g4) holds
   // q16[query x15 of the block][32 s + 8 g4 .. +8]
@@ -549,27 +578,8 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
           }
     }
   }
-  if (lane == 0) hitcnt[wave_gid] = wcnt;
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(myprog + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// File every logged survivor under its query: cand[qid][slot] with slot from an atomic counter.
-// grid = number of wave logs, block = 64.
-__global__ __launch_bounds__(64) void scatter_hits_kernel(const Hit* __restrict__ hitlog, const uint32_t* __restrict__ hitcnt,
-                                                          Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap,
-                                                          uint32_t* __restrict__ overflow, uint32_t* __restrict__ log_overflow,
-                                                          uint32_t n_rows) {
-  const uint32_t w = blockIdx.x;
-  uint32_t n = hitcnt[w];
-  if (n > FILTER_LOGCAP) { if (threadIdx.x == 0) *log_overflow = 1u; n = FILTER_LOGCAP; }
-  for (uint32_t i = threadIdx.x; i < n; i += 64) {
-    const Hit h = hitlog[static_cast<uint64_t>(w) * FILTER_LOGCAP + i];
-    if (h.row >= n_rows) continue;                 // zero rows that pad the corpus to whole tiles
-    const uint32_t slot = atomicAdd(&cnt[h.qid], 1u);
-    if (slot < cap) cand[static_cast<uint64_t>(h.qid) * cap + slot] = Cand{h.score, h.row};
-    else overflow[h.qid] = 1u;
-  }
+  scatter_own_log(mylog, wcnt, sa, lane);
 }
 
 // ================================================================================================
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
     const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
     const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qinv,
-    Hit* __restrict__ hitlog, uint32_t* __restrict__ hitcnt, uint32_t aux) {
+    Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t aux) {
   constexpr int KSTEPS = DIM / 32;                 // v_mfma_i32_32x32x32_i8: K = 32
   constexpr int ROW_BYTES = DIM;
   constexpr int DATA_BYTES = FILTER_ROWS * ROW_BYTES;
@@ -659,7 +669,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
   const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
   const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
   const uint32_t NT = t_hi - t_lo;
-  if (NT == 0) { if (!BOOT && lane == 0) hitcnt[wave_gid] = 0; return; }
+  if (NT == 0) return;
 
   // stationary operand: 32 queries x two int8 planes x all of K, in AGPRs.  Lane (r31,hsel) holds bytes
   // [32 s + 16 hsel, +16) of its query -- the same k-slice the A fragment holds.
@@ -782,8 +792,8 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
       }
     }
   }
-  if (!BOOT && lane == 0) hitcnt[wave_gid] = wcnt;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (!BOOT) scatter_own_log(mylog, wcnt, sa, lane);
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -57,7 +57,7 @@ struct nvdb_hip_ctx {
   _Float16* shadow16 = nullptr;                    // fp32 corpus only: fp16 copy streamed by the MFMA filter
 
   // grow-only workspace
-  DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, hitcnt, prog;
+  DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, prog;
   DevBuf rq, rcand, rout_ids, rout_dist;           // refine
 
   // options
@@ -216,7 +216,7 @@ nvdb_status launch_select(nvdb_hip_ctx* c, hipStream_t s, uint32_t nq, uint32_t 
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_MAX_CAP * sizeof(Cand)));
     c->lds_attr_set.insert(fn);
   }
-  select_kernel<<<nq, cap <= 2048 ? 64 : 256, cap * sizeof(Cand), s>>>(static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap, k, slack,
+  select_kernel<<<nq, 256, cap * sizeof(Cand), s>>>(static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap, k, slack,
                                                    static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->overflow.p), mode,
                                                    c->row_base, reinterpret_cast<unsigned long long*>(out_ids), out_scores, out_k);
   HIPCHK(c, hipGetLastError());
@@ -238,6 +238,11 @@ nvdb_status launch_rescore(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uin
 #undef NVDB_LAUNCH_RS
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
+}
+
+ScatterArgs scatter_args(nvdb_hip_ctx* c, uint32_t cap) {
+  return ScatterArgs{static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), static_cast<uint32_t*>(c->overflow.p),
+                     static_cast<uint32_t*>(c->misc.p) + 1, cap, static_cast<uint32_t>(c->n)};
 }
 
 // dims the fp16 MFMA kernels are instantiated for (multiples of 128 up to 768: the 64 queries' fragments must fit 384 registers)
@@ -269,7 +274,6 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
   if (nwg == 0) nwg = QT;
   nvdb_status st;
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
-  if ((st = ensure(c, c->hitcnt, static_cast<size_t>(nwg) * 4 * 4))) return st;
   if (m16) {
     // only when the kernel's XCD-aware mapping is active (the QT workgroups of a row stream share an XCD label)
     const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
@@ -284,25 +288,21 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
       filter_f16_m16_kernel<DIM, 6, true><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
                                                                 static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                                 static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
-                                                                static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p),
+                                                                static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap),
                                                                 static_cast<uint32_t*>(c->prog.p), static_cast<uint32_t>(c->opt_sync_every - 1),
                                                                 static_cast<uint32_t>(c->opt_sync_lead));
     } else {
       filter_f16_m16_kernel<DIM><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
                                                        static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                        static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
-                                                       static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p), nullptr, 0u, 0u);
+                                                       static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), nullptr, 0u, 0u);
     }
   }
   else
     filter_f16_kernel<DIM, NB><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
                                                      static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                      static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
-                                                     static_cast<Hit*>(c->hitlog.p), static_cast<uint32_t*>(c->hitcnt.p), 0u);
-  HIPCHK(c, hipGetLastError());
-  scatter_hits_kernel<<<nwg * 4, 64, 0, s>>>(static_cast<const Hit*>(c->hitlog.p), static_cast<const uint32_t*>(c->hitcnt.p),
-                                             static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap,
-                                             static_cast<uint32_t*>(c->overflow.p), static_cast<uint32_t*>(c->misc.p) + 1, static_cast<uint32_t>(c->n));
+                                                     static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), 0u);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -320,17 +320,12 @@ nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
   if (nwg == 0) nwg = QT;
   nvdb_status st;
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
-  if ((st = ensure(c, c->hitcnt, static_cast<size_t>(nwg) * 4 * 4))) return st;
   const signed char* qhi = static_cast<const signed char*>(c->q16.p);
   const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * DIM;
   filter_i8_kernel<DIM><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
                                               static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                               static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
-                                              static_cast<uint32_t*>(c->hitcnt.p), 0u);
-  HIPCHK(c, hipGetLastError());
-  scatter_hits_kernel<<<nwg * 4, 64, 0, s>>>(static_cast<const Hit*>(c->hitlog.p), static_cast<const uint32_t*>(c->hitcnt.p),
-                                             static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap,
-                                             static_cast<uint32_t*>(c->overflow.p), static_cast<uint32_t*>(c->misc.p) + 1, static_cast<uint32_t>(c->n));
+                                              scatter_args(c, cap), 0u);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -350,7 +345,7 @@ nvdb_status launch_boot_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_
   filter_f16_kernel<DIM, NB, 7><<<nwg, 256, lds, s>>>(filter_rows_f16(c), 0, n0, static_cast<const _Float16*>(c->q16.p), nq, QT,
                                                       static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                       static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->cand.p),
-                                                      static_cast<uint32_t*>(c->hitcnt.p), cap);
+                                                      scatter_args(c, cap), cap);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -370,7 +365,7 @@ nvdb_status launch_boot_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint
   filter_i8_kernel<DIM, true><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, 0, n0, qhi, qlo, nq, QT,
                                                     static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                     static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->cand.p),
-                                                    static_cast<uint32_t*>(c->hitcnt.p), cap);
+                                                    scatter_args(c, cap), cap);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -433,10 +428,9 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   if ((st = ensure(c, c->overflow, nq_pad * 4))) return st;
   if ((st = ensure(c, c->cand, static_cast<size_t>(nq) * cap * sizeof(Cand)))) return st;
   if ((st = ensure(c, c->misc, 64))) return st;
-  HIPCHK(c, hipMemsetAsync(c->cnt.p, 0, nq_pad * 4, s));
-  HIPCHK(c, hipMemsetAsync(c->overflow.p, 0, nq_pad * 4, s));
-  HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 16, s));
-  fill_u32_kernel<<<(nq_pad + 255) / 256, 256, 0, s>>>(static_cast<uint32_t*>(c->thr.p), 0xFF800000u, nq_pad);   // -inf
+  init_search_kernel<<<(nq_pad + 255) / 256, 256, 0, s>>>(static_cast<uint32_t*>(c->cnt.p), static_cast<uint32_t*>(c->overflow.p),
+                                                          static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->misc.p), nq_pad);
+  HIPCHK(c, hipGetLastError());
 
   c->stats = nvdb_hip_scan_stats{};
   c->stats.path = static_cast<uint32_t>(path);
@@ -469,7 +463,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   HIPCHK(c, hipGetLastError());
   const float* slack = static_cast<const float*>(c->slack.p);
   // Whole tiles: a corpus this library allocated is zero-padded to a multiple of 32 rows (the padded rows are
-  // dropped by scatter_hits_kernel); for an adopted corpus the ragged tail goes to the exact kernel.
+  // dropped when the wave files its survivors); for an adopted corpus the ragged tail goes to the exact kernel.
   const bool padded = c->owned || c->dtype == NVDB_DTYPE_F32;      // the fp16 shadow is always ours, hence padded
   const uint32_t n_al = padded ? (n + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS : n / FILTER_ROWS * FILTER_ROWS;
   uint32_t r = 0;
@@ -566,7 +560,7 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   free_corpus(c);
   for (DevBuf* b : {&c->q32, &c->q16, &c->qscale, &c->qinv, &c->ebound, &c->slack, &c->thr, &c->cnt, &c->overflow, &c->cand,
-                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->hitcnt, &c->prog, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
+                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->prog, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& k : c->klaunch) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
@@ -836,7 +830,7 @@ nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* c, int variant, uint32_t
       if (r == 1) HIPCHK(c, hipEventRecord(e0, c->stream));                                                                    \
       filter_f16_kernel<768, 2, V, RG><<<nwg, 256, lds, c->stream>>>(static_cast<const _Float16*>(c->rows), 0, n_al, static_cast<const _Float16*>(c->q16.p), nq, QT, \
           static_cast<const float*>(inf.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),     \
-          static_cast<uint32_t*>(c->hitcnt.p), 0u);                                                                            \
+          scatter_args(c, c->last_cap), 0u);                                                                                   \
     }                                                                                                                          \
   }
   switch (variant) {
