@@ -327,7 +327,15 @@ __global__ __launch_bounds__(256) void select_kernel(
       if (i < m) {
         my[u] = e[i];
         uint32_t r = 0;
-        for (uint32_t j = 0; j < m; ++j) { const Cand o = e[j]; r += better(o.score, o.row, my[u].score, my[u].row) ? 1u : 0u; }
+        uint32_t j = 0;
+        for (; j + 8 <= m; j += 8) {              // 8 independent broadcast reads in flight
+          Cand o[8];
+#pragma unroll
+          for (int v = 0; v < 8; ++v) o[v] = e[j + v];
+#pragma unroll
+          for (int v = 0; v < 8; ++v) r += better(o[v].score, o[v].row, my[u].score, my[u].row) ? 1u : 0u;
+        }
+        for (; j < m; ++j) { const Cand o = e[j]; r += better(o.score, o.row, my[u].score, my[u].row) ? 1u : 0u; }
         rk[u] = r;
         if (r == k - 1) s_kth = my[u].score;
       }
