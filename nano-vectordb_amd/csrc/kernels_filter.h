@@ -403,6 +403,28 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
 // spin; nothing is ever read through this channel except the progress counters themselves.
 constexpr uint32_t SYNC_MAX_SPINS = 400;
 
+// Sibling rendezvous (see filter_f16_m16_kernel): wave 0 publishes its tile index and waits while it is more than
+// `lead` tiles ahead of the slowest workgroup of its row stream; bounded, and abandoned after 3 time-outs.
+__device__ __forceinline__ void sibling_rendezvous(uint32_t* myprog, uint32_t qt, uint32_t t, uint32_t lead, uint32_t& strikes, int lane) {
+  if (lane == 0) __hip_atomic_store(myprog + qt, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t spin = 0; strikes < 3; ++spin) {
+    if (spin == SYNC_MAX_SPINS) { ++strikes; break; }
+    uint32_t p0, p1, p2, p3, p4, p5, p6, p7;
+    asm volatile("s_load_dwordx8 s[88:95], %8, 0x0 glc\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 %0, s88\n\ts_mov_b32 %1, s89\n\ts_mov_b32 %2, s90\n\ts_mov_b32 %3, s91\n\t"
+                 "s_mov_b32 %4, s92\n\ts_mov_b32 %5, s93\n\ts_mov_b32 %6, s94\n\ts_mov_b32 %7, s95"
+                 : "=s"(p0), "=s"(p1), "=s"(p2), "=s"(p3), "=s"(p4), "=s"(p5), "=s"(p6), "=s"(p7)
+                 : "s"(myprog)
+                 : "memory", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
+    uint32_t lo = p0 < p1 ? p0 : p1;
+    lo = lo < p2 ? lo : p2; lo = lo < p3 ? lo : p3; lo = lo < p4 ? lo : p4;
+    lo = lo < p5 ? lo : p5; lo = lo < p6 ? lo : p6; lo = lo < p7 ? lo : p7;
+    if (lo >= t || t - lo <= lead) break;             // nobody is more than `lead` tiles behind me
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+
 template <int DIM, int RING = 6, bool SYNC = false>
 __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
@@ -495,24 +517,8 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   uint32_t sync_strikes = 0;                       // rendezvous that timed out; after 3 this workgroup stops waiting
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
-      if (wave == 0 && (t & sync_mask) == 0) {           // wave 0 only; the per-tile barrier holds the other waves back
-        if (lane == 0) __hip_atomic_store(myprog + qt, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t spin = 0; sync_strikes < 3; ++spin) {
-          if (spin == SYNC_MAX_SPINS) { ++sync_strikes; break; }
-          uint32_t p0, p1, p2, p3, p4, p5, p6, p7;
-          asm volatile("s_load_dwordx8 s[88:95], %8, 0x0 glc\n\ts_waitcnt lgkmcnt(0)\n\t"
-                       "s_mov_b32 %0, s88\n\ts_mov_b32 %1, s89\n\ts_mov_b32 %2, s90\n\ts_mov_b32 %3, s91\n\t"
-                       "s_mov_b32 %4, s92\n\ts_mov_b32 %5, s93\n\ts_mov_b32 %6, s94\n\ts_mov_b32 %7, s95"
-                       : "=s"(p0), "=s"(p1), "=s"(p2), "=s"(p3), "=s"(p4), "=s"(p5), "=s"(p6), "=s"(p7)
-                       : "s"(myprog)
-                       : "memory", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
-          uint32_t lo = p0 < p1 ? p0 : p1;
-          lo = lo < p2 ? lo : p2; lo = lo < p3 ? lo : p3; lo = lo < p4 ? lo : p4;
-          lo = lo < p5 ? lo : p5; lo = lo < p6 ? lo : p6; lo = lo < p7 ? lo : p7;
-          if (lo >= t || t - lo <= sync_lead) break;      // nobody is more than sync_lead tiles behind me
-          __builtin_amdgcn_s_sleep(8);
-        }
-      }
+      // wave 0 only; the per-tile barrier holds the other waves back
+      if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(myprog, qt, t, sync_lead, sync_strikes, lane);
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -639,12 +645,12 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
 
 // BOOT = true: bootstrap build (see filter_f16_kernel VAR 7): best (score,row) per tile and query -> cand lists
 // (hitlog then points at the candidate lists, aux is their stride).
-template <int DIM, bool BOOT = false, int RING = 6>
+template <int DIM, bool BOOT = false, int RING = 6, bool SYNC = false>
 __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
     const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
     const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qinv,
-    Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t aux) {
+    Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t aux, uint32_t* __restrict__ prog, uint32_t sync_mask, uint32_t sync_lead) {
   constexpr int KSTEPS = DIM / 32;                 // v_mfma_i32_32x32x32_i8: K = 32
   constexpr int ROW_BYTES = DIM;
   constexpr int DATA_BYTES = FILTER_ROWS * ROW_BYTES;
@@ -720,7 +726,11 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
   uint32_t wcnt = 0;
   Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
 
+  uint32_t sync_strikes = 0;
   for (uint32_t t = 0; t < NT; ++t) {
+    if constexpr (SYNC) {
+      if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(prog + static_cast<uint64_t>(stream) * 8, qt, t, sync_lead, sync_strikes, lane);
+    }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
     __builtin_amdgcn_s_barrier();
     const uint32_t next_row0 = tile_row0(t + 2), next_buf = (t + 2) % FILTER_STAGES;
@@ -792,6 +802,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
       }
     }
   }
+  if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(prog + static_cast<uint64_t>(stream) * 8 + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if constexpr (!BOOT) scatter_own_log(mylog, wcnt, sa, lane);
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

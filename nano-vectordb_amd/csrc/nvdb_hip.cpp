@@ -322,10 +322,26 @@ nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
   const signed char* qhi = static_cast<const signed char*>(c->q16.p);
   const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * DIM;
-  filter_i8_kernel<DIM><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
-                                              static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
-                                              static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
-                                              scatter_args(c, cap), 0u);
+  const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+  if (sync) {
+    if ((st = ensure(c, c->prog, static_cast<size_t>(nwg) * 8 * 4))) return st;
+    HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, static_cast<size_t>(nwg) * 8 * 4, s));
+    const void* fs = reinterpret_cast<const void*>(filter_i8_kernel<DIM, false, 6, true>);
+    if (!c->lds_attr_set.count(fs)) {
+      HIPCHK(c, hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      c->lds_attr_set.insert(fs);
+    }
+    filter_i8_kernel<DIM, false, 6, true><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
+                                                                static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
+                                                                static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
+                                                                scatter_args(c, cap), 0u, static_cast<uint32_t*>(c->prog.p),
+                                                                static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));
+  } else {
+    filter_i8_kernel<DIM><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
+                                                static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
+                                                static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
+                                                scatter_args(c, cap), 0u, nullptr, 0u, 0u);
+  }
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -365,7 +381,7 @@ nvdb_status launch_boot_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint
   filter_i8_kernel<DIM, true><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, 0, n0, qhi, qlo, nq, QT,
                                                     static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                     static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->cand.p),
-                                                    scatter_args(c, cap), cap);
+                                                    scatter_args(c, cap), cap, nullptr, 0u, 0u);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
