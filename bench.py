@@ -190,11 +190,9 @@ def main():
     st = ctx.search_check()                                    # raises on overflow / bound violation
     parity = "skipped"
     if rank == 0:
-        # the filter path must reproduce the exact kernel bit for bit, and the returned scores must be
-        # the reference's CPU scores of the returned rows (oracle dot on rows copied back from HBM)
-        import pyoracle as po
-        orc = po.Oracle()
-        # local search only (no collective here: the other ranks are not in this branch)
+        # Self-check without the oracle (the oracle only serves the cpu_baseline leg here; tests/ pin the exact
+        # fp32 kernel against it): the MFMA filter path must reproduce the exact fp32-order kernel bit for bit.
+        # Local search only -- no collective in this branch, the other ranks are not in it.
         ctx.search_batch_dev(qdev[:B].data_ptr(), B, K, out_ids.data_ptr(), out_sc.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         fi, fs = out_ids[:8].cpu().numpy().astype(np.uint64), out_sc[:8].cpu().numpy()
@@ -204,17 +202,9 @@ def main():
         ei, es = out_ids[:8].cpu().numpy().astype(np.uint64), out_sc[:8].cpu().numpy()
         ctx.set_option("path", args.path)
         ok = np.array_equal(fi, ei) and np.array_equal(fs.view(np.uint32), es.view(np.uint32))
-        for qi in range(4):
-            for j in range(K):
-                row, rsc = ctx.download_rows(int(fi[qi, j]) - lo, 1)
-                if args.dtype == "f16":
-                    s = orc.lib.oracle_dot_f32_f16base(po._p(qhost[qi], po._f32p), row.ctypes.data, D)
-                else:
-                    s = orc.lib.oracle_dot_f32_i8base(po._p(qhost[qi], po._f32p), row.ctypes.data, D, float(rsc[0]))
-                ok = ok and np.float32(s).view(np.uint32) == fs[qi, j].view(np.uint32)
-        parity = "ok" if ok else "FAILED"
+        parity = "ok: MFMA path == exact fp32-order kernel (ids and score bits, 8 queries)" if ok else "FAILED"
         if not ok:
-            raise SystemExit("parity self-check failed: filter path != exact path / oracle scores")
+            raise SystemExit("parity self-check failed: filter path != exact path")
     barrier()
 
     merge_check = None
