@@ -419,3 +419,57 @@ def test_full_size_10M_properties(oracle, dtype, tag):
         c.close()
     mi, ms = nvdb_amd.merge_topk_host(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
     assert np.array_equal(mi, ids) and np.array_equal(ms.view(np.uint32), sc.view(np.uint32))
+
+
+# ----------------------------------------------------------------------------- device-buffer entry points (torch as plumbing)
+@pytest.mark.parametrize("tag", ["f16", "i8", "f32"])
+def test_adopted_corpus_and_device_buffers(oracle, tag):
+    """nvdb_hip_adopt_corpus (corpus already in HBM, not owned, NOT padded -> ragged tail on the exact kernel) and
+    nvdb_hip_search_batch_dev / nvdb_hip_search_check (queries and results in HBM, caller's stream)."""
+    import torch
+    n, d, nq, k = 50000 + 21, 768, 96, 10
+    dt = {"f16": nvdb_amd.DT_F16, "i8": nvdb_amd.DT_I8, "f32": nvdb_amd.DT_F32}[tag]
+    base, scales = nvdb_amd.synth_corpus(SEED + 70, 0, n, d, dt)
+    queries = nvdb_amd.synth_rows_f32(SEED + 71, 0, nq, d)
+    dev = torch.device("cuda", 0)
+    view = base.view(np.int16) if tag == "f16" else base
+    t_rows = torch.from_numpy(view).to(dev)
+    t_scales = torch.from_numpy(scales).to(dev) if scales is not None else None
+    t_q = torch.from_numpy(queries).to(dev)
+    t_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    t_sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    ctx = nvdb_amd.HipContext(0)
+    ctx.adopt_corpus(t_rows.data_ptr(), n, d, dt, t_scales.data_ptr() if t_scales is not None else None, row_base=1000)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx.search_batch_dev(t_q.data_ptr(), nq, k, t_ids.data_ptr(), t_sc.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    st = ctx.search_check()
+    assert st["path"] == 2 and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    ids = t_ids.cpu().numpy().astype(np.uint64) - np.uint64(1000)
+    sc = t_sc.cpu().numpy()
+    _check_against_oracle(oracle, base, {"f16": po.DT_F16, "i8": po.DT_I8, "f32": po.DT_F32}[tag], scales, queries, ids, sc, k,
+                          f"adopt/{tag}")
+    # the last rows (ragged tail, < 32) must be reachable: query = one of them
+    qtail = (oracle.f16_to_f32(base[n - 3]) if tag == "f16" else
+             (base[n - 3].astype(np.float32) * scales[n - 3] if tag == "i8" else base[n - 3]))[None, :].astype(np.float32)
+    t_q1 = torch.from_numpy(qtail).to(dev)
+    ctx.search_batch_dev(t_q1.data_ptr(), 1, k, t_ids.data_ptr(), t_sc.data_ptr(), None)
+    torch.cuda.synchronize()
+    ctx.search_check()
+    assert int(t_ids[0, 0].item()) == 1000 + n - 3
+    ctx.close()
+    # refine with device buffers
+    if tag != "i8":
+        ctx = nvdb_amd.HipContext(0)
+        ctx.adopt_corpus(t_rows.data_ptr(), n, d, dt, None)
+        rs = np.random.RandomState(2)
+        cand = rs.randint(0, n, size=(nq, 200)).astype(np.uint32)
+        t_c = torch.from_numpy(cand.view(np.int32)).to(dev)
+        t_oi = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        t_od = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        ctx.refine_l2_topk_dev(t_q.data_ptr(), t_c.data_ptr(), nq, 200, k, t_oi.data_ptr(), t_od.data_ptr(), None)
+        torch.cuda.synchronize()
+        oid, od = oracle.refine(base, po.DT_F16 if tag == "f16" else po.DT_F32, queries, cand, k, mode=0)
+        assert np.array_equal(t_oi.cpu().numpy().view(np.uint32), oid) and np.array_equal(t_od.cpu().numpy().view(np.uint32), od.view(np.uint32))
+        ctx.close()
