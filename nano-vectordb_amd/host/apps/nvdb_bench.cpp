@@ -64,10 +64,16 @@ int main(int argc, char** argv) {
 
   nvdb::FlatIndex st_index(&base);
   nvdb::FlatIndexOMP omp_index(&base);
+  // NVDB_GPU_DEVICES="0,1,2,3": row-shard the corpus over these devices (default: device 0 only)
+  std::vector<int> devices;
+  if (const char* dv = std::getenv("NVDB_GPU_DEVICES")) { std::string s(dv); size_t p = 0; while (p < s.size()) { size_t e = s.find(',', p); if (e == std::string::npos) e = s.size(); devices.push_back(std::stoi(s.substr(p, e - p))); p = e + 1; } }
   std::unique_ptr<nvdb::FlatIndexHIP> hip_index;
-  if (gpu) hip_index = std::make_unique<nvdb::FlatIndexHIP>(&base, 0);    // one-time upload, not timed (like the reference's base H2D)
+  std::unique_ptr<nvdb::FlatIndexHIPSharded> hip_sharded;
+  if (gpu && devices.size() > 1) hip_sharded = std::make_unique<nvdb::FlatIndexHIPSharded>(&base, devices);
+  else if (gpu) hip_index = std::make_unique<nvdb::FlatIndexHIP>(&base, devices.empty() ? 0 : devices[0]);    // one-time upload, not timed (like the reference's base H2D)
 
   auto run_query = [&](const float* q) {
+    if (hip_sharded) return hip_sharded->search_topk_dot(q, k);
     if (gpu) return hip_index->search_topk_dot(q, k);
     return mode == "omp" ? omp_index.search_topk_dot(q, k) : st_index.search_topk_dot(q, k);
   };
@@ -87,8 +93,9 @@ int main(int argc, char** argv) {
       const uint32_t b = static_cast<uint32_t>(std::min<uint64_t>(batch_q, Q - q0));
       const auto t0 = Clock::now();
       if (gpu) {
-        const auto res = hip_index->search_topk_dot_batch(query.vector_ptr_f32(q0), b, k);
-        gpu_kernel_ms += hip_index->last_kernel_ms();
+        const auto res = hip_sharded ? hip_sharded->search_topk_dot_batch(query.vector_ptr_f32(q0), b, k)
+                                     : hip_index->search_topk_dot_batch(query.vector_ptr_f32(q0), b, k);
+        if (hip_index) gpu_kernel_ms += hip_index->last_kernel_ms();
         lat.push_back(ms_between(t0, Clock::now()));
         const size_t ke = res.size() / b;
         for (uint32_t i = 0; i < b && ke; ++i) sink = sink + res[i * ke].score;
@@ -121,7 +128,7 @@ int main(int argc, char** argv) {
       const auto t0 = Clock::now();
       const auto topk = run_query(query.vector_ptr_f32(qi));
       lat.push_back(ms_between(t0, Clock::now()));
-      if (gpu) gpu_kernel_ms += hip_index->last_kernel_ms();
+      if (hip_index) gpu_kernel_ms += hip_index->last_kernel_ms();
       if (!topk.empty()) sink = sink + topk[0].score;
     }
   }
@@ -154,7 +161,7 @@ int main(int argc, char** argv) {
   std::cout << "batch_q=" << batch_q << " tile_vecs=" << tile_vecs << " prefetch_dist=" << prefetch_dist << "\n";
   if (gpu) {
     const double passes = batch_q > 1 ? static_cast<double>((Q + batch_q - 1) / batch_q) : static_cast<double>(Q);
-    std::cout << "gpu_kernel_ms_total=" << gpu_kernel_ms << " gpu_passes=" << static_cast<uint64_t>(passes)
+    std::cout << "gpu_shards=" << (hip_sharded ? hip_sharded->shards() : 1) << " gpu_kernel_ms_total=" << gpu_kernel_ms << " gpu_passes=" << static_cast<uint64_t>(passes)
               << " gpu_algorithmic_GBps=" << (gpu_kernel_ms > 0 ? passes * bytes_per_query * 1e-6 / gpu_kernel_ms : 0.0) << "\n";
   }
   return 0;

@@ -34,4 +34,25 @@ class FlatIndexHIP {
   mutable double last_kernel_ms_ = 0.0;
 };
 
+// Row-sharded flat index over several GPUs of one node (the reference has no multi-GPU path): shard g holds the
+// contiguous rows [g*N/G, (g+1)*N/G) on devices[g] with global ids; a batch is searched on all shards concurrently
+// (one host thread per GPU) and the per-shard top-k lists are merged on the host in the canonical order, which makes
+// the result identical to the single-GPU result.  (bench.py does the same across processes with an RCCL all-gather.)
+class FlatIndexHIPSharded {
+ public:
+  FlatIndexHIPSharded(const VectorDataset* base, const std::vector<int>& devices);
+  ~FlatIndexHIPSharded();
+  FlatIndexHIPSharded(const FlatIndexHIPSharded&) = delete;
+  FlatIndexHIPSharded& operator=(const FlatIndexHIPSharded&) = delete;
+
+  std::vector<SearchResult> search_topk_dot(const float* q, uint32_t k) const { return search_topk_dot_batch(q, 1, k); }
+  std::vector<SearchResult> search_topk_dot_batch(const float* queries, uint32_t nq, uint32_t k) const;
+  size_t shards() const { return ctx_.size(); }
+
+ private:
+  std::vector<nvdb_hip_ctx*> ctx_;
+  uint64_t n_ = 0;
+  uint32_t dim_ = 0;
+};
+
 }  // namespace nvdb

@@ -101,6 +101,10 @@ def test_gpu_modes_of_the_tools(files, golden):
         out = run("nvdb_bench", files["b16"], files["q"], 10, "gpu", *extra)
         assert re.search(r"sink=(\S+)", out).group(1) == re.search(r"sink=(\S+)", cpu).group(1)
         assert "gpu_kernel_ms_total=" in out.splitlines()[-1]
+    # row-sharded over "two GPUs" (the same device twice on this box): same sink as the unsharded run
+    out = run("nvdb_bench", files["b16"], files["q"], 10, "gpu", "0", "1", "8", env={"NVDB_GPU_DEVICES": "0,0,0"})
+    assert re.search(r"sink=(\S+)", out).group(1) == re.search(r"sink=(\S+)", cpu).group(1)
+    assert "gpu_shards=3" in out.splitlines()[-1]
 
 
 @pytest.mark.gpu
