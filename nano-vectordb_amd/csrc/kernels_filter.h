@@ -515,44 +515,32 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   uint32_t* myprog = prog + static_cast<uint64_t>(stream) * 8;
 
   uint32_t sync_strikes = 0;                       // rendezvous that timed out; after 3 this workgroup stops waiting
-
-  // The tile loop is rotated: "wait for tile t+1, barrier, start its first LDS reads" sits BETWEEN the MFMAs of
-  // tile t and the threshold compares of tile t, so the LDS latency of the next tile's first fragments (and the
-  // MFMA->VALU wait states) are covered by the epilogue instead of opening every tile with a bubble.
-  auto stage_ptr = [&](uint32_t t) -> const char* { return smem + (t % FILTER_STAGES) * STAGE_BYTES; };
-  auto read_a = [&](const char* stage, int u) -> float4_t {        // u = 2*s + mb
-    const int s = u >> 1, mb = u & 1;
-    return *reinterpret_cast<const float4_t*>(stage + (a16 ^ ((s & 3) << 6)) + (s >> 2) * 256 + mb * 16 * ROW_BYTES);
-  };
-  auto enter_tile = [&](uint32_t t) {              // tile t has landed for everybody; buffer (t+2)%3 is free
+  for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
       // wave 0 only; the per-tile barrier holds the other waves back
       if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(myprog, qt, t, sync_lead, sync_strikes, lane);
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     __builtin_amdgcn_s_barrier();
-  };
-
-  float4_t ar[RING];
-  enter_tile(0);
-  if (wave_has_queries) {
-#pragma unroll
-    for (int u = 0; u < RING - 1; ++u) ar[u] = read_a(stage_ptr(0), u);
-  }
-  for (uint32_t t = 0; t < NT; ++t) {
     const char* next_tile = tile_ptr(t + 2);
     const uint32_t next_buf = (t + 2) % FILTER_STAGES;
-    const char* stage = stage_ptr(t);
-    if (!wave_has_queries) {                       // padding-only wave: keep streaming and keep the barrier cadence
+    const char* stage = smem + (t % FILTER_STAGES) * STAGE_BYTES;
+    if (!wave_has_queries) {
 #pragma unroll
       for (int i = 0; i < PPW; ++i) issue_piece(next_tile, next_buf, i);
-      if (t + 1 < NT) enter_tile(t + 1);
       continue;
     }
+    auto read_a = [&](int u) -> float4_t {        // u = 2*s + mb
+      const int s = u >> 1, mb = u & 1;
+      return *reinterpret_cast<const float4_t*>(stage + (a16 ^ ((s & 3) << 6)) + (s >> 2) * 256 + mb * 16 * ROW_BYTES);
+    };
+    float4_t ar[RING];
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u) ar[u] = read_a(u);
     float4_t acc[2][4];
 #pragma unroll
     for (int u = 0; u < NREAD; ++u) {
-      if (u + RING - 1 < NREAD) ar[(u + RING - 1) % RING] = read_a(stage, u + RING - 1);
+      if (u + RING - 1 < NREAD) ar[(u + RING - 1) % RING] = read_a(u + RING - 1);
       const float4_t a = ar[u % RING];
       const int s = u >> 1, mb = u & 1;
 #pragma unroll
@@ -568,17 +556,8 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
       }
       if (u % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_tile, next_buf, u / PIECE_EVERY);
     }
-    // next tile: rendezvous / wait / barrier, then its first fragment reads go out before this tile's epilogue
-    if (t + 1 < NT) {
-      enter_tile(t + 1);
-      const char* nstage = stage_ptr(t + 1);
-#pragma unroll
-      for (int u = 0; u < RING - 1; ++u) ar[u] = read_a(nstage, u);
-    }
-    // >= 16 wait states between the last MFMA and the first VALU read of an accumulator (the compiler does not see
-    // inside the asm); the instructions above usually cover them already
-    asm volatile("s_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
-                              "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                                          "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
     bool any = false;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
