@@ -43,14 +43,15 @@ constexpr int FILTER_STAGES = 3;
 //   slack[q]   = 2 * ebound[q]
 // grid = nq_pad (multiple of 256), block = 256.  Pad queries get zeros.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim,
+__global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim, uint32_t sdim,
                                                        float max_row_norm, float rel, float abs_per_norm, _Float16* __restrict__ q16,
                                                        float* __restrict__ qscale, float* __restrict__ qinv,
                                                        float* __restrict__ ebound, float* __restrict__ slack) {
   __shared__ float red_max[4], red_ss[4];
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  // sdim >= dim: row stride of q16 = the (zero-padded) dim the filter kernel is instantiated for
   if (q >= nq) {
-    for (uint32_t i = tid; i < dim; i += 256) q16[static_cast<uint64_t>(q) * dim + i] = static_cast<_Float16>(0.f);
+    for (uint32_t i = tid; i < sdim; i += 256) q16[static_cast<uint64_t>(q) * sdim + i] = static_cast<_Float16>(0.f);
     if (tid == 0) { qscale[q] = 1.f; qinv[q] = 1.f; ebound[q] = 0.f; slack[q] = 0.f; }
     return;
   }
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__
     e = e > 100 ? 100 : (e < -100 ? -100 : e);
   }
   const float sc = ldexpf(1.f, e);
-  for (uint32_t i = tid; i < dim; i += 256) q16[static_cast<uint64_t>(q) * dim + i] = static_cast<_Float16>(src[i] * sc);
+  for (uint32_t i = tid; i < sdim; i += 256) q16[static_cast<uint64_t>(q) * sdim + i] = static_cast<_Float16>(i < dim ? src[i] * sc : 0.f);
   if (tid == 0) {
     const float nrm = sqrtf(ss) * 1.0001f;
     // abs_per_norm: absolute rounding of the corpus side (fp16 shadow of an fp32 corpus: subnormal halves)
@@ -844,13 +845,19 @@ __global__ __launch_bounds__(256) void gen_rows_kernel(uint64_t seed, uint64_t r
   }
 }
 
-// fp32 corpus -> fp16 "shadow" copy for the MFMA filter (round-to-nearest-even) + max |x| (float bits via
-// atomicMax).  The fp32 rows stay the arbiter: every survivor is re-scored from them in the reference's order.
-__global__ __launch_bounds__(256) void shadow_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t count,
-                                                         uint32_t* __restrict__ maxabs_bits) {
+// "shadow" copy streamed by the MFMA filter when the corpus itself cannot be: an fp32 corpus (rounded to fp16,
+// round-to-nearest-even) and/or a dim the kernels are not instantiated for (rows zero-padded to sdim).  Also
+// returns max |x| (float bits via atomicMax).  The original rows stay the arbiter: every survivor is re-scored
+// from them in the reference's order.
+template <typename SrcT>
+__global__ __launch_bounds__(256) void shadow_f16_kernel(const SrcT* __restrict__ src, _Float16* __restrict__ dst, size_t n,
+                                                         uint32_t dim, uint32_t sdim, uint32_t* __restrict__ maxabs_bits) {
   float mx = 0.f;
+  const size_t count = n * sdim;
   for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<size_t>(gridDim.x) * 256) {
-    const float v = src[i];
+    const size_t r = i / sdim;
+    const uint32_t c = static_cast<uint32_t>(i - r * sdim);
+    const float v = c < dim ? static_cast<float>(src[r * dim + c]) : 0.f;
     dst[i] = static_cast<_Float16>(v);
     mx = fmaxf(mx, fabsf(v));
   }

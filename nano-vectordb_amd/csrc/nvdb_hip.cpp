@@ -54,7 +54,8 @@ struct nvdb_hip_ctx {
   uint32_t dim = 0, dtype = 0;
   uint64_t row_base = 0;
   float max_norm = 0.f;
-  _Float16* shadow16 = nullptr;                    // fp32 corpus only: fp16 copy streamed by the MFMA filter
+  _Float16* shadow16 = nullptr;                    // fp16 copy streamed by the MFMA filter (fp32 corpus and/or padded dim)
+  uint32_t fdim = 0;                               // dim the filter kernels run at (>= dim; == dim without padding)
 
   // grow-only workspace
   DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, prog;
@@ -125,8 +126,11 @@ void free_corpus(nvdb_hip_ctx* c) {
     if (c->scales) (void)hipFree(c->scales);
   }
   if (c->shadow16) { (void)hipFree(c->shadow16); c->shadow16 = nullptr; }
-  c->rows = nullptr; c->scales = nullptr; c->owned = false; c->n = 0; c->dim = 0; c->dtype = 0; c->max_norm = 0.f;
+  c->rows = nullptr; c->scales = nullptr; c->owned = false; c->n = 0; c->dim = 0; c->fdim = 0; c->dtype = 0; c->max_norm = 0.f;
 }
+
+// dims the fp16 MFMA kernels are instantiated for (multiples of 128 up to 768: the 64 queries' fragments must fit 384 registers)
+bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128; }
 
 nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   nvdb_status st = ensure(c, c->misc, 64);
@@ -142,19 +146,26 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   HIPCHK(c, hipMemcpyAsync(&h, bits, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memcpy(&c->max_norm, &h, 4);
-  // fp32 corpus with a filter-capable dim: fp16 shadow copy (skipped when values would overflow a half)
-  if (c->dtype == NVDB_DTYPE_F32 && (c->dim == 768 || c->dim == 512 || c->dim == 384 || c->dim == 256 || c->dim == 128) && c->opt_f32_shadow) {
-    const size_t count = static_cast<size_t>(c->n) * c->dim;
-    const size_t pad = static_cast<size_t>(FILTER_ROWS) * c->dim * 2 + 4096;
+  // Which dim do the MFMA kernels run at?  fp16 corpus with an instantiated dim: the corpus itself, no copy.
+  // fp32 corpus, or fp16 with another dim <= 768: an fp16 shadow copy, rows zero-padded to the next instantiated
+  // dim (skipped when values would overflow a half).  int8: its own instantiations, no shadow.
+  c->fdim = c->dim;
+  if (c->dtype != NVDB_DTYPE_I8 && c->dim <= 768 && !(c->dtype == NVDB_DTYPE_F16 && f16_filter_dim(c->dim)) && c->opt_f32_shadow) {
+    uint32_t sdim = 128;
+    while (!f16_filter_dim(sdim) || sdim < c->dim) sdim += 128;
+    const size_t count = static_cast<size_t>(c->n) * sdim;
+    const size_t pad = static_cast<size_t>(FILTER_ROWS) * sdim * 2 + 4096;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow16), count * 2 + pad));
     HIPCHK(c, hipMemsetAsync(reinterpret_cast<char*>(c->shadow16) + count * 2, 0, pad, c->stream));
     HIPCHK(c, hipMemsetAsync(bits, 0, 4, c->stream));
-    shadow_f16_kernel<<<4096, 256, 0, c->stream>>>(static_cast<const float*>(c->rows), c->shadow16, count, bits);
+    if (c->dtype == NVDB_DTYPE_F32) shadow_f16_kernel<float><<<4096, 256, 0, c->stream>>>(static_cast<const float*>(c->rows), c->shadow16, c->n, c->dim, sdim, bits);
+    else shadow_f16_kernel<_Float16><<<4096, 256, 0, c->stream>>>(static_cast<const _Float16*>(c->rows), c->shadow16, c->n, c->dim, sdim, bits);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(&h, bits, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float maxabs; std::memcpy(&maxabs, &h, 4);
     if (!(maxabs < 60000.f)) { (void)hipFree(c->shadow16); c->shadow16 = nullptr; }
+    else c->fdim = sdim;
   }
   return NVDB_OK;
 }
@@ -245,16 +256,13 @@ ScatterArgs scatter_args(nvdb_hip_ctx* c, uint32_t cap) {
                      static_cast<uint32_t*>(c->misc.p) + 1, cap, static_cast<uint32_t>(c->n)};
 }
 
-// dims the fp16 MFMA kernels are instantiated for (multiples of 128 up to 768: the 64 queries' fragments must fit 384 registers)
-bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128; }
-
 // what the fp16 MFMA kernels stream: the corpus itself, or the fp16 shadow of an fp32 corpus
 const _Float16* filter_rows_f16(const nvdb_hip_ctx* c) {
-  return c->dtype == NVDB_DTYPE_F32 ? c->shadow16 : static_cast<const _Float16*>(c->rows);
+  return c->shadow16 ? c->shadow16 : static_cast<const _Float16*>(c->rows);
 }
 
 bool filter_supported(const nvdb_hip_ctx* c) {
-  if (c->dtype == NVDB_DTYPE_F16) return f16_filter_dim(c->dim);
+  if (c->dtype == NVDB_DTYPE_F16) return f16_filter_dim(c->dim) || c->shadow16 != nullptr;
   if (c->dtype == NVDB_DTYPE_F32) return c->shadow16 != nullptr;
   if (c->dtype == NVDB_DTYPE_I8) return c->dim == 768 || c->dim == 512 || c->dim == 256;   // int8 rows: stride % 256 == 0
   return false;
@@ -393,7 +401,7 @@ nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq
     if (c->dim == 256) return launch_boot_i8_dim<256>(c, s, n0, nq, QT, cap);
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 boot kernel: unsupported dim");
   }
-#define NVDB_BOOT_DIM(D) if (c->dim == D) return nb == 1 ? launch_boot_dim<D, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<D, 2>(c, s, n0, nq, QT, cap)
+#define NVDB_BOOT_DIM(D) if (c->fdim == D) return nb == 1 ? launch_boot_dim<D, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<D, 2>(c, s, n0, nq, QT, cap)
   NVDB_BOOT_DIM(768); NVDB_BOOT_DIM(512); NVDB_BOOT_DIM(384); NVDB_BOOT_DIM(256); NVDB_BOOT_DIM(128);
 #undef NVDB_BOOT_DIM
   return fail(c, NVDB_ERR_UNSUPPORTED, "boot kernel: unsupported dim");
@@ -411,7 +419,7 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
     if (c->dim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 filter kernel: unsupported dim");
   }
-#define NVDB_FILTER_DIM(D) if (c->dim == D) return nb == 1 ? launch_filter_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, cap)
+#define NVDB_FILTER_DIM(D) if (c->fdim == D) return nb == 1 ? launch_filter_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, cap)
   NVDB_FILTER_DIM(768); NVDB_FILTER_DIM(512); NVDB_FILTER_DIM(384); NVDB_FILTER_DIM(256); NVDB_FILTER_DIM(128);
 #undef NVDB_FILTER_DIM
   return fail(c, NVDB_ERR_UNSUPPORTED, "filter kernel: unsupported dim");
@@ -429,7 +437,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t n = static_cast<uint32_t>(c->n);
   int path = force_path ? force_path : static_cast<int>(c->opt_path);
   if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
-  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim 768/512/384/256/128 or an int8 corpus with dim 768/512/256");
+  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 768 or an int8 corpus with dim 768/512/256");
 
   uint32_t cap = c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : (nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
@@ -460,7 +468,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   }
 
   // ---- path 2: MFMA filter ----------------------------------------------------------------------
-  if ((st = ensure(c, c->q16, static_cast<size_t>(nq_pad) * c->dim * 2))) return st;
+  if ((st = ensure(c, c->q16, static_cast<size_t>(nq_pad) * c->fdim * 2))) return st;
   if ((st = ensure(c, c->qscale, nq_pad * 4))) return st;
   if ((st = ensure(c, c->qinv, nq_pad * 4))) return st;
   if ((st = ensure(c, c->ebound, nq_pad * 4))) return st;
@@ -472,7 +480,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
                                           static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
   else
     // fp32 corpus: the shadow adds 2^-11 relative (normal halves) and <= 2^-25 absolute per element (subnormal halves)
-    prep_q16_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->max_norm, c->dtype == NVDB_DTYPE_F32 ? FILTER_REL_F16 + 4.9e-4f : FILTER_REL_F16,
+    prep_q16_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->fdim, c->max_norm, c->dtype == NVDB_DTYPE_F32 ? FILTER_REL_F16 + 4.9e-4f : FILTER_REL_F16,
                                            c->dtype == NVDB_DTYPE_F32 ? 3.0e-8f * std::sqrt(static_cast<float>(c->dim)) : 0.f, static_cast<_Float16*>(c->q16.p),
                                            static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
                                            static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
@@ -480,7 +488,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const float* slack = static_cast<const float*>(c->slack.p);
   // Whole tiles: a corpus this library allocated is zero-padded to a multiple of 32 rows (the padded rows are
   // dropped when the wave files its survivors); for an adopted corpus the ragged tail goes to the exact kernel.
-  const bool padded = c->owned || c->dtype == NVDB_DTYPE_F32;      // the fp16 shadow is always ours, hence padded
+  const bool padded = c->owned || c->shadow16 != nullptr;          // a shadow copy is always ours, hence padded
   const uint32_t n_al = padded ? (n + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS : n / FILTER_ROWS * FILTER_ROWS;
   uint32_t r = 0;
   uint64_t size;
@@ -512,7 +520,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     if (acct) {
       HIPCHK(c, hipEventCreate(&kl.e0)); HIPCHK(c, hipEventCreate(&kl.e1));
       kl.flops = 2.0 * nq * static_cast<double>(std::min(hi, n) - r) * c->dim;   // algorithmic: real queries, real rows
-      kl.bytes = static_cast<double>(std::min(hi, n) - r) * (c->dim * (c->dtype == NVDB_DTYPE_F32 ? 2.0 : static_cast<double>(bpe_of(c->dtype))) + (c->dtype == NVDB_DTYPE_I8 ? 4.0 : 0.0));   // rows streamed once
+      kl.bytes = static_cast<double>(std::min(hi, n) - r) * (c->dtype == NVDB_DTYPE_I8 ? c->dim + 4.0 : c->fdim * 2.0);   // rows streamed once
       HIPCHK(c, hipEventRecord(kl.e0, s));
     }
     if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev), s)); }
@@ -794,7 +802,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
     timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
     timing->threads = 256; timing->nwarps = 4; timing->K = k;
-    timing->shmem_bytes = total.path == 2 ? static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->dim * 2 : 0;
+    timing->shmem_bytes = total.path == 2 ? static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * (c->dtype == NVDB_DTYPE_I8 ? 1 : 2) : 0;
   }
   if (total.bound_violations) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated; results were recomputed on the exact path");
   return NVDB_OK;

@@ -250,6 +250,28 @@ def test_filter_and_exact_paths_agree_on_other_dims(ctx, oracle, d, nq):
     _check_against_oracle(oracle, base, po.DT_F16, None, queries, res[2][0], res[2][1], k, f"dim{d}")
 
 
+@pytest.mark.parametrize("tag,d,nq", [("f16", 100, 70), ("f16", 300, 33), ("f16", 600, 200), ("f32", 200, 64), ("f32", 760, 9)])
+def test_filter_path_on_zero_padded_shadow_for_odd_dims(ctx, oracle, tag, d, nq):
+    """Dims the MFMA kernels are not instantiated for: the filter streams an fp16 shadow whose rows are
+    zero-padded to the next instantiated dim; survivors are re-scored from the ORIGINAL rows in the reference's
+    order (incl. its tail rules, simd_dot.cpp:26-49, 95-150), so ids and score bits still match the CPU path."""
+    n, k = 50000 + 11, 10
+    dt = nvdb_amd.DT_F16 if tag == "f16" else nvdb_amd.DT_F32
+    ctx.generate_corpus(SEED + 70, n, d, dt)
+    base, _ = nvdb_amd.synth_corpus(SEED + 70, 0, n, d, dt)
+    queries = nvdb_amd.synth_rows_f32(SEED + 71, 0, nq, d)
+    queries[0] = oracle.f16_to_f32(base[777]) if tag == "f16" else base[777]
+    res = {}
+    for path in (1, 2):
+        ctx.set_option("path", path)
+        res[path] = ctx.search_batch(queries, k)
+        st = ctx.stats()
+        assert st["path"] == path and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    ctx.set_option("path", 0)
+    assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1].view(np.uint32), res[2][1].view(np.uint32))
+    _check_against_oracle(oracle, base, po.DT_F16 if tag == "f16" else po.DT_F32, None, queries, res[2][0], res[2][1], k, f"pad/{tag}/d{d}")
+
+
 def test_overflow_falls_back_to_exact_path(ctx, oracle):
     """Adversarial order (rows sorted by score ascending for the query) overflows the candidate
     lists; the library must notice and still return the exact answer."""
