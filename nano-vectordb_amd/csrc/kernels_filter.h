@@ -426,7 +426,9 @@ __device__ __forceinline__ void sibling_rendezvous(uint32_t* myprog, uint32_t qt
 }
 
 
-template <int DIM, int RING = 6, bool SYNC = false>
+// STAMP: diagnostic build only (nvdb_hip_debug_clock): wave 0 stamps s_memtime / s_memrealtime around the tile
+// loop and stores the two differences behind the progress counters, where nothing else reads them.
+template <int DIM, int RING = 6, bool SYNC = false, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
     uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
@@ -516,6 +518,8 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   uint32_t* myprog = prog + static_cast<uint64_t>(stream) * 8;
 
   uint32_t sync_strikes = 0;                       // rendezvous that timed out; after 3 this workgroup stops waiting
+  uint64_t stamp_c = 0, stamp_r = 0;
+  if constexpr (STAMP) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
       // wave 0 only; the per-tile barrier holds the other waves back
@@ -583,6 +587,13 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
               wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
             }
           }
+    }
+  }
+  if constexpr (STAMP) {
+    const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c, dr = __builtin_amdgcn_s_memrealtime() - stamp_r;
+    if (wave == 0 && lane == 0) {
+      uint64_t* out = reinterpret_cast<uint64_t*>(prog + static_cast<uint64_t>(gridDim.x) * 8) + static_cast<uint64_t>(blockIdx.x) * 2;
+      out[0] = dc; out[1] = dr;
     }
   }
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(myprog + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -6,7 +6,8 @@
 // mode: st | omp  (CPU, per query; batch_q > 1 = bench-side batching as in the reference)
 //       gpu | hip (GPU; batch_q = queries per nvdb_hip_search_batch call; tile_vecs/prefetch_dist are
 //                  accepted and echoed but have no meaning on the GPU)
-// async/pool (alternative CPU threading of the same arithmetic) are not provided: exit code 3.
+//       async | pool (CPU; per-call worker threads / persistent pinned team; pool also takes batch_q > 1,
+//                  async does not -- as in the reference, apps/nvdb_bench.cpp:335-346)
 // Every line the reference prints is printed unchanged; GPU-only lines are appended after them.
 #include <algorithm>
 #include <chrono>
@@ -21,6 +22,7 @@
 
 #include "nvdb/flat_index.h"
 #include "nvdb/flat_index_hip.h"
+#include "nvdb/flat_index_threads.h"
 #include "nvdb/simd_dot.h"
 
 #if defined(_OPENMP)
@@ -60,10 +62,13 @@ int main(int argc, char** argv) {
     std::cerr << "Dim mismatch: base.dim=" << base.dim() << ", query.dim=" << query.dim() << "\n";
     return 2;
   }
-  if (!gpu && mode != "st" && mode != "omp") { std::cerr << "Unknown or unsupported mode: " << mode << " (st|omp|gpu)\n"; return 3; }
+  if (!gpu && mode != "st" && mode != "omp" && mode != "async" && mode != "pool") { std::cerr << "Unknown mode: " << mode << " (st|omp|async|pool|gpu)\n"; return 3; }
 
   nvdb::FlatIndex st_index(&base);
   nvdb::FlatIndexOMP omp_index(&base);
+  nvdb::FlatIndexAsync async_index(&base);
+  std::unique_ptr<nvdb::FlatIndexPool> pool_index;
+  if (mode == "pool") pool_index = std::make_unique<nvdb::FlatIndexPool>(&base, threads);
   // NVDB_GPU_DEVICES="0,1,2,3": row-shard the corpus over these devices (default: device 0 only)
   std::vector<int> devices;
   if (const char* dv = std::getenv("NVDB_GPU_DEVICES")) { std::string s(dv); size_t p = 0; while (p < s.size()) { size_t e = s.find(',', p); if (e == std::string::npos) e = s.size(); devices.push_back(std::stoi(s.substr(p, e - p))); p = e + 1; } }
@@ -75,6 +80,8 @@ int main(int argc, char** argv) {
   auto run_query = [&](const float* q) {
     if (hip_sharded) return hip_sharded->search_topk_dot(q, k);
     if (gpu) return hip_index->search_topk_dot(q, k);
+    if (mode == "async") return async_index.search_topk_dot(q, k, threads);
+    if (mode == "pool") return pool_index->search_topk_dot(q, k);
     return mode == "omp" ? omp_index.search_topk_dot(q, k) : st_index.search_topk_dot(q, k);
   };
 
@@ -87,6 +94,10 @@ int main(int argc, char** argv) {
   volatile float sink = 0.f;
   double gpu_kernel_ms = 0.0;
   const auto t_all0 = Clock::now();
+  if (batch_q > 1 && mode == "async") {
+    std::cerr << "batch_q>1 supported only for mode=st/omp/pool/gpu (bench-side batching).\n";
+    return 3;
+  }
   if (batch_q > 1) {
     const uint32_t dim = base.dim(), dt = base.dtype();
     for (uint64_t q0 = 0; q0 < Q; q0 += static_cast<uint64_t>(batch_q)) {
@@ -115,6 +126,19 @@ int main(int argc, char** argv) {
           }
           for (auto& p : part) for (uint32_t i = 0; i < b; ++i) best[i].merge_from(p[i].raw());
 #endif
+        } else if (mode == "pool") {
+          // the same tile loop on a team of std::threads: tiles dealt round-robin, per-thread lists, serial merge
+          std::vector<std::vector<nvdb::TopKBuffer>> part(static_cast<size_t>(threads), std::vector<nvdb::TopKBuffer>(b, nvdb::TopKBuffer(k)));
+          std::vector<std::thread> team;
+          for (int w = 0; w < threads; ++w)
+            team.emplace_back([&, w] {
+              auto& mine = part[static_cast<size_t>(w)];
+              for (int64_t t = w; t < ntiles; t += threads)
+                for (uint64_t r = static_cast<uint64_t>(t) * T; r < std::min<uint64_t>(N, static_cast<uint64_t>(t + 1) * T); ++r)
+                  for (uint32_t i = 0; i < b; ++i) mine[i].consider(r, nvdb::score_query_base_at(base, query.vector_ptr_f32(q0 + i), r, dim, dt));
+            });
+          for (auto& w : team) w.join();
+          for (auto& p : part) for (uint32_t i = 0; i < b; ++i) best[i].merge_from(p[i].raw());
         } else {
           for (uint64_t r = 0; r < N; ++r)
             for (uint32_t i = 0; i < b; ++i) best[i].consider(r, nvdb::score_query_base_at(base, query.vector_ptr_f32(q0 + i), r, dim, dt));

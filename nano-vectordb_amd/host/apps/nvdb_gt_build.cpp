@@ -1,20 +1,24 @@
 // nvdb_gt_build -- exact top-k ids of every query -> .gtbin (reference apps/nvdb_gt_build.cpp:22-129).
-// GT_MODE = gpu (default here when a GPU is present) | omp | st ; WARMUP as in the reference.
+// GT_MODE = gpu (default here when a GPU is present) | omp | st | async | pool ; WARMUP as in the reference.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "nvdb/flat_index.h"
 #include "nvdb/flat_index_hip.h"
+#include "nvdb/flat_index_threads.h"
 #include "nvdb/gtbin_format.h"
 #include "nvdb_hip.h"
 
 int main(int argc, char** argv) {
   if (argc < 5) {
-    std::cerr << "Usage: nvdb_gt_build <base.vecbin> <query.vecbin> <k> <out.gtbin>\nEnv:\n  GT_MODE=gpu|omp|st\n  WARMUP=2\n";
+    std::cerr << "Usage: nvdb_gt_build <base.vecbin> <query.vecbin> <k> <out.gtbin>\nEnv:\n  GT_MODE=gpu|omp|st|async|pool\n  WARMUP=2\n";
     return 1;
   }
   const uint32_t k = static_cast<uint32_t>(std::stoul(argv[3]));
@@ -46,8 +50,14 @@ int main(int argc, char** argv) {
   } else {
     nvdb::FlatIndex st(&base);
     nvdb::FlatIndexOMP omp(&base);
+    nvdb::FlatIndexAsync async(&base);
+    const int nthreads = std::max(1u, std::thread::hardware_concurrency());
+    std::unique_ptr<nvdb::FlatIndexPool> pool;
+    if (mode == "pool") pool = std::make_unique<nvdb::FlatIndexPool>(&base, nthreads);
     for (uint64_t qi = 0; qi < Q; ++qi) {
-      const auto r = mode == "st" ? st.search_topk_dot(query.vector_ptr_f32(qi), k) : omp.search_topk_dot(query.vector_ptr_f32(qi), k);
+      const float* qv = query.vector_ptr_f32(qi);
+      const auto r = mode == "st" ? st.search_topk_dot(qv, k) : mode == "async" ? async.search_topk_dot(qv, k, nthreads)
+                   : mode == "pool" ? pool->search_topk_dot(qv, k) : omp.search_topk_dot(qv, k);
       if (!store(qi, r.data(), r.size())) return 5;
       if ((qi + 1) % 200 == 0) std::cout << "GT " << (qi + 1) << "/" << Q << "\n";
     }

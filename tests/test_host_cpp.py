@@ -53,14 +53,15 @@ def test_nvdb_search_cpu_prints_the_reference_lines(files, golden):
 
 
 def test_nvdb_gt_build_cpu_modes_write_the_reference_gtbin(files, golden):
-    for mode in ("st", "omp"):
+    for mode in ("st", "omp", "async", "pool"):
         run("nvdb_gt_build", files["b16"], files["q"], 10, files["gt"], env={"GT_MODE": mode, "OMP_NUM_THREADS": "3"})
         ids, meta = po.read_gtbin(files["gt"])
         assert np.array_equal(ids, golden["main768_gtbin_f16_ids"])
         assert np.fromfile(files["gt"], dtype=np.uint8)[:64].tobytes() == bytes(golden["main768_gtbin_raw"])
 
 
-@pytest.mark.parametrize("mode,extra", [("st", []), ("omp", ["2"]), ("omp", ["2", "1", "4", "512", "0"])])
+@pytest.mark.parametrize("mode,extra", [("st", []), ("omp", ["2"]), ("omp", ["2", "1", "4", "512", "0"]),
+                                        ("async", ["3"]), ("pool", ["3"]), ("pool", ["2", "1", "4", "512", "0"])])
 def test_nvdb_bench_cpu_output_lines(files, mode, extra):
     out = run("nvdb_bench", files["b16"], files["q"], 10, mode, *extra, env={"OMP_NUM_THREADS": "2"})
     lines = out.strip().splitlines()
@@ -88,6 +89,10 @@ def test_nvdb_bench_rejects_bad_input(files, built):
     po.write_vecbin(p, base32, po.DT_F32)
     r = subprocess.run([os.path.join(BIN, "nvdb_bench"), p, files["q"], "3"], capture_output=True, text=True)
     assert r.returncode == 2 and "Dim mismatch" in r.stderr
+    r = subprocess.run([os.path.join(BIN, "nvdb_bench"), files["b16"], files["q"], "3", "async", "2", "0", "4"], capture_output=True, text=True)
+    assert r.returncode == 3 and "batch_q>1 supported only" in r.stderr       # reference: uncaught runtime_error, apps/nvdb_bench.cpp:345
+    r = subprocess.run([os.path.join(BIN, "nvdb_bench"), files["b16"], files["q"], "3", "warp"], capture_output=True, text=True)
+    assert r.returncode == 3 and "Unknown mode" in r.stderr
 
 
 # ------------------------------------------------------------------------------------------------ GPU
