@@ -178,8 +178,9 @@ nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* ctx, int variant, uint32
 /* Developer aid: the clock the chip holds inside the production fp16 d=768 filter kernel.  Launches a diagnostic
  * build (identical code + one s_memtime / s_memrealtime stamp pair around the tile loop of every workgroup) back to
  * back for `seconds`, then reports out4 = { ms per launch (last 8), median, min, max over workgroups of
- * delta(s_memtime) / delta(s_memrealtime) x 100 MHz in GHz }.  Same preconditions as the call above. */
-nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* ctx, uint32_t nq, float seconds, float* out4);
+ * delta(s_memtime) / delta(s_memrealtime) x 100 MHz in GHz }.  variant: 0 = the production loop; timing-only
+ * ablations 1 = no direct-to-LDS loads, 5 = no LDS reads, 15 = neither.  Same preconditions as the call above. */
+nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* ctx, int variant, uint32_t nq, float seconds, float* out4);
 
 /* ---------------------------------------------------------------------------------------------
  * exact-L2 refine (rerank of R candidates per query) -- replaces nvdb::cuda_l2_topk_batch

@@ -114,6 +114,13 @@ __device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_
                : "=&s"(keep) : "v"(voff), "s"(lds_off), "s"(sbase) : "memory");
 }
 
+// max of three without the canonicalising v_max the compiler wraps around fmaxf of values it did not produce itself
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // One survivor of the filter, logged by the wave that found it (16 bytes, one dwordx4 store).
 struct Hit { float score; uint32_t row; uint32_t qid; uint32_t pad; };
 constexpr uint32_t FILTER_LOGCAP = 512;            // entries per wave and launch
@@ -428,7 +435,9 @@ __device__ __forceinline__ void sibling_rendezvous(uint32_t* myprog, uint32_t qt
 
 // STAMP: diagnostic build only (nvdb_hip_debug_clock): wave 0 stamps s_memtime / s_memrealtime around the tile
 // loop and stores the two differences behind the progress counters, where nothing else reads them.
-template <int DIM, int RING = 6, bool SYNC = false, bool STAMP = false>
+// VAR (with STAMP only; results are wrong): 1 = no direct-to-LDS loads in the loop, 5 = no LDS reads (MFMA on whatever
+// the ring registers hold), 15 = neither (bare MFMA stream + barrier + epilogue), 16 = 15 without the epilogue compares, 17 = 16 without the barrier.
+template <int DIM, int RING = 6, bool SYNC = false, bool STAMP = false, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
     uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
@@ -525,8 +534,9 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
       // wave 0 only; the per-tile barrier holds the other waves back
       if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(myprog, qt, t, sync_lead, sync_strikes, lane);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    __builtin_amdgcn_s_barrier();
+    constexpr bool NO_GLDS = (VAR == 1 || VAR >= 15), NO_READ = (VAR == 5 || VAR >= 15), NO_EPI = (VAR >= 16), NO_BAR = (VAR >= 17);
+    if constexpr (!NO_GLDS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    if constexpr (!NO_BAR) __builtin_amdgcn_s_barrier();
     const char* next_tile = tile_ptr(t + 2);
     const uint32_t next_buf = (t + 2) % FILTER_STAGES;
     const char* stage = smem + (t % FILTER_STAGES) * STAGE_BYTES;
@@ -540,12 +550,16 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
       return *reinterpret_cast<const float4_t*>(stage + (a16 ^ ((s & 3) << 6)) + (s >> 2) * 256 + mb * 16 * ROW_BYTES);
     };
     float4_t ar[RING];
+    if constexpr (NO_READ) {
 #pragma unroll
-    for (int u = 0; u < RING - 1; ++u) ar[u] = read_a(u);
+      for (int u = 0; u < RING; ++u) ar[u] = bqv[u];          // random, non-trivial operand bits
+    }
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u) if constexpr (!NO_READ) ar[u] = read_a(u);
     float4_t acc[2][4];
 #pragma unroll
     for (int u = 0; u < NREAD; ++u) {
-      if (u + RING - 1 < NREAD) ar[(u + RING - 1) % RING] = read_a(u + RING - 1);
+      if constexpr (!NO_READ) { if (u + RING - 1 < NREAD) ar[(u + RING - 1) % RING] = read_a(u + RING - 1); }
       const float4_t a = ar[u % RING];
       const int s = u >> 1, mb = u & 1;
 #pragma unroll
@@ -559,17 +573,24 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
           else NVDB_MFMA16_ACC_V(acc[mb][nb], a, bqv[f >= NFRAG_A ? f - NFRAG_A : 0]);
         }
       }
-      if (u % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_tile, next_buf, u / PIECE_EVERY);
+      if constexpr (!NO_GLDS) { if (u % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_tile, next_buf, u / PIECE_EVERY); }
     }
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
                                           "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
-    bool any = false;
+    if constexpr (NO_EPI) continue;
+    // "does any of my 32 scores reach its query's threshold": a max tree per query block (v_max3_f32), one subtract
+    // per block, one compare in all -- 23 vector instructions.  (32 compares into SGPR pairs + 32 s_or_b64 cost
+    // ~770 cycles per tile, a quarter of the tile's MFMA time: profiles/r01d_clock_ablation.txt.)
+    float dmax[4];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) any |= (acc[mb][nb][r] >= thr_s[nb]);
+    for (int nb = 0; nb < 4; ++nb) {
+      float m = vmax3(acc[0][nb][0], acc[0][nb][1], acc[0][nb][2]);
+      m = vmax3(m, acc[0][nb][3], acc[1][nb][0]);
+      m = vmax3(m, acc[1][nb][1], acc[1][nb][2]);
+      m = vmax3(m, acc[1][nb][3], acc[1][nb][3]);
+      dmax[nb] = m - thr_s[nb];                      // >= 0 iff m >= thr (a difference of floats never rounds across 0)
+    }
+    const bool any = vmax3(vmax3(dmax[0], dmax[1], dmax[2]), dmax[3], dmax[3]) >= 0.f;
     if (__builtin_amdgcn_ballot_w64(any)) {
       const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
 #pragma unroll

@@ -883,7 +883,7 @@ nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* c, int variant, uint32_t
   return NVDB_OK;
 }
 
-nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* c, uint32_t nq, float seconds, float* out4) {
+nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* c, int variant, uint32_t nq, float seconds, float* out4) {
   if (!c || !out4) return NVDB_ERR_INVALID;
   if (!c->rows || c->dtype != NVDB_DTYPE_F16 || c->dim != 768 || !c->q16.p) return fail(c, NVDB_ERR_UNSUPPORTED, "debug: run a path-2 search on an fp16 d=768 corpus first");
   if (nq <= 128 || nq > (c->last_nq + 255u) / 256u * 256u) return fail(c, NVDB_ERR_UNSUPPORTED, "debug: 128 < nq <= the last search's padded batch");
@@ -899,26 +899,37 @@ nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* c, uint32_t nq, float seconds, fl
   if ((st = ensure(c, c->prog, prog_bytes + stamp_bytes))) return st;
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
   constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * 768 * 2;
-  const void* fn = reinterpret_cast<const void*>(filter_f16_m16_kernel<768, 6, true, true>);
-  HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
   const uint32_t n_al = static_cast<uint32_t>(c->n / FILTER_ROWS * FILTER_ROWS);
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
   const auto t_start = std::chrono::steady_clock::now();
   float ms = 0.f;
-  uint32_t launches = 0;
+  const uint32_t burst = 8;
+#define NVDB_CLK_LAUNCH(V)                                                                                                       \
+  {                                                                                                                              \
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_f16_m16_kernel<768, 6, true, true, V>),                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                           \
+    for (uint32_t r = 0; r < burst; ++r) {                                                                                       \
+      HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, prog_bytes, c->stream));                                                         \
+      filter_f16_m16_kernel<768, 6, true, true, V><<<nwg, 256, lds, c->stream>>>(                                                \
+          static_cast<const _Float16*>(c->rows), 0, n_al, static_cast<const _Float16*>(c->q16.p), nq, QT,                        \
+          static_cast<const float*>(inf.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),        \
+          static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap), static_cast<uint32_t*>(c->prog.p),                       \
+          static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));                                \
+    }                                                                                                                            \
+  }
   for (;;) {                                       // back-to-back launches until `seconds` have passed, the last 8 timed
     const bool last = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_start).count() >= seconds;
-    const uint32_t burst = 8;
     if (last) HIPCHK(c, hipEventRecord(e0, c->stream));
-    for (uint32_t r = 0; r < burst; ++r) {
-      HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, prog_bytes, c->stream));
-      filter_f16_m16_kernel<768, 6, true, true><<<nwg, 256, lds, c->stream>>>(
-          static_cast<const _Float16*>(c->rows), 0, n_al, static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(inf.p),
-          static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap),
-          static_cast<uint32_t*>(c->prog.p), static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));
+    switch (variant) {
+      case 0: NVDB_CLK_LAUNCH(0) break;
+      case 1: NVDB_CLK_LAUNCH(1) break;
+      case 5: NVDB_CLK_LAUNCH(5) break;
+      case 15: NVDB_CLK_LAUNCH(15) break;
+      case 16: NVDB_CLK_LAUNCH(16) break;
+      case 17: NVDB_CLK_LAUNCH(17) break;
+      default: return fail(c, NVDB_ERR_INVALID, "debug: unknown variant");
     }
-    launches += burst;
     HIPCHK(c, hipGetLastError());
     if (last) {
       HIPCHK(c, hipEventRecord(e1, c->stream));
@@ -929,6 +940,7 @@ nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* c, uint32_t nq, float seconds, fl
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+#undef NVDB_CLK_LAUNCH
   std::vector<uint64_t> stamps(static_cast<size_t>(nwg) * 2);
   HIPCHK(c, hipMemcpy(stamps.data(), static_cast<const char*>(c->prog.p) + prog_bytes, stamp_bytes, hipMemcpyDeviceToHost));
   std::vector<float> ghz;
@@ -939,7 +951,6 @@ nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* c, uint32_t nq, float seconds, fl
   out4[1] = ghz.empty() ? 0.f : ghz[ghz.size() / 2];
   out4[2] = ghz.empty() ? 0.f : ghz.front();
   out4[3] = ghz.empty() ? 0.f : ghz.back();
-  (void)launches;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(inf.p);
   return NVDB_OK;

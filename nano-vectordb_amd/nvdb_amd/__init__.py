@@ -87,7 +87,7 @@ def load_library():
     L.nvdb_hip_collect_kernel_times.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                 C.POINTER(C.c_double)]
     L.nvdb_hip_debug_filter_variant.argtypes = [vp, C.c_int, u32, u32, f32p]
-    L.nvdb_hip_debug_clock.argtypes = [vp, u32, C.c_float, f32p]
+    L.nvdb_hip_debug_clock.argtypes = [vp, C.c_int, u32, C.c_float, f32p]
     L.nvdb_hip_merge_topk_dev.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp]
     L.nvdb_hip_merge_topk_strided_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, u32, u32, u32, vp, vp, vp]
     L.nvdb_merge_topk_host.argtypes = [vp, vp, u32, u32, u32, vp, vp]
