@@ -362,10 +362,17 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(acc[nb]));
     } else {
+      // max tree per query block, then one compare (see filter_f16_m16_kernel)
+      float d[NB];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb) {
+        float m = vmax3(acc[nb][0], acc[nb][1], acc[nb][2]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) any |= (acc[nb][r] >= thr_s[nb]);
+        for (int r = 3; r < 15; r += 2) m = vmax3(m, acc[nb][r], acc[nb][r + 1]);
+        m = vmax3(m, acc[nb][15], acc[nb][15]);
+        d[nb] = m - thr_s[nb];
+      }
+      any = (NB == 2 ? vmax3(d[0], d[NB - 1], d[NB - 1]) : d[0]) >= 0.f;
     }
     if (__builtin_amdgcn_ballot_w64(any)) {
       // rare path: log the survivors in this wave's own region (plain 16-byte stores, no atomics,
@@ -777,6 +784,11 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
     auto read_a = [&](int s) -> float4_t {
       return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256);
     };
+    // this tile's 16 row scales for my lanes: read now, used in the epilogue (their latency hides behind the MFMAs)
+    const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 1024);
+    float4 sc4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sc4[j] = *reinterpret_cast<const float4*>(sc_lds + 8 * j + 4 * hsel);
     float4_t ar[RING];
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(s);
@@ -793,20 +805,23 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc_hi), "+v"(acc_lo));
 
     // epilogue: f = (128*H + L) * scale_row  compared with thr/s_q ; rows (r&3) + 8*(r>>2) + 4*hsel
-    const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 1024);
+    // 128*H + L in int32 (|.| < 768*127*(127*128 + 64) < 2^31), one conversion: RN(128 H + L), the value the
+    // fp32 fma(float(H), 128, float(L)) gives as well (float(H) is exact below 2^24)
+    static_assert(DIM <= 768, "int32 range of 128*H + L");
     float fv[16];
-    bool any = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float4 sc4 = *reinterpret_cast<const float4*>(sc_lds + 8 * j + 4 * hsel);
-      const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+      const float scv[4] = {sc4[j].x, sc4[j].y, sc4[j].z, sc4[j].w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * j + i;
-        fv[r] = __builtin_fmaf(static_cast<float>(acc_hi[r]), 128.f, static_cast<float>(acc_lo[r])) * scv[i];
-        any |= fv[r] >= thr_s;
+        fv[r] = static_cast<float>(acc_hi[r] * 128 + acc_lo[r]) * scv[i];
       }
     }
+    float fmx = vmax3(fv[0], fv[1], fv[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) fmx = vmax3(fmx, fv[r], fv[r + 1]);
+    const bool any = vmax3(fmx, fv[15], fv[15]) >= thr_s;
     if constexpr (BOOT) {
       const uint32_t tile = t_lo + t;
       const uint32_t row0b = row_lo + tile * FILTER_ROWS;
