@@ -321,7 +321,7 @@ def main():
                     c.search_batch_dev(qd.data_ptr(), b, K, oi.data_ptr(), os_.data_ptr(), strm)
                 torch.cuda.synchronize()
                 el = (time.perf_counter() - t0) / reps
-                c.search_check()
+                timed_passes.last_stats = c.search_check()
                 return el
             # (1) HBM-bound point of the same fp16 corpus: batch 64
             el = timed_passes(ctx, qdev, 64)
@@ -333,7 +333,11 @@ def main():
             for bb in (B, 64):
                 el = timed_passes(c8, qdev, bb)
                 extras[f"int8_batch{bb}"] = {"workload": f"int8+scale flat-scan top-{K}, N={N} d={D}, batch={bb}", "qps": bb / el, "ms_per_pass": el * 1e3,
-                                             "hbm_GBps": N * (D + 4) / 1e9 / el, "hbm_frac": N * (D + 4) / 1e9 / el / PEAK_HBM_GBPS}
+                                             "hbm_GBps": N * (D + 4) / 1e9 / el, "hbm_frac": N * (D + 4) / 1e9 / el / PEAK_HBM_GBPS,
+                                             "algorithmic_TOPs": 2.0 * bb * N * D / el / 1e12,
+                                             "two_stage": {"tiles_past_quick_test": timed_passes.last_stats.get("i8_stage1_tiles"),
+                                                           "lo_plane_blocks": timed_passes.last_stats.get("i8_stage2_blocks"),
+                                                           "wave_tiles": (N // 32) * ((bb + 63) // 64)} if bb > 128 else None}
             # recall@10 of the int8 corpus against the fp32 corpus' exact top-10 (500K-row prefix, 64 queries)
             nr = min(N, 500_000)
             c32 = nvdb_amd.HipContext(local_rank)

@@ -70,6 +70,8 @@ typedef struct nvdb_hip_scan_stats {
   uint32_t bound_violations;   /* |filter - exact| > bound seen by the rescore (must be 0)        */
   float    filter_kernel_ms;   /* sum of hipEvent times of the dominant kernel's launches         */
   float    other_kernel_ms;    /* prep + select + rescore + merge                                  */
+  uint32_t i8_stage1_tiles;    /* int8 two-stage kernel: (wave, tile) pairs that went past the hi-plane quick test */
+  uint32_t i8_stage2_blocks;   /* ... 32-query blocks for which the lo plane was multiplied after all           */
 } nvdb_hip_scan_stats;
 
 /* ---------------------------------------------------------------------------------------------

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void init_search_kernel(uint32_t* __restrict__
                                                           float* __restrict__ thr, uint32_t* __restrict__ misc, uint32_t nq_pad) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < nq_pad) { cnt[i] = 0; overflow[i] = 0; thr[i] = NEG_INF; }
-  if (i < 4) misc[i] = 0;
+  if (i < 8) misc[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -646,12 +646,13 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
                                                       float max_row_norm, signed char* __restrict__ qhi,
                                                       signed char* __restrict__ qlo, float* __restrict__ qscale,
                                                       float* __restrict__ qinv, float* __restrict__ ebound,
-                                                      float* __restrict__ slack) {
+                                                      float* __restrict__ slack, float* __restrict__ qdelta) {
   __shared__ float red_max[4], red_ss[4];
+  __shared__ uint32_t red_lo[4];
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
   if (q >= nq) {
     for (uint32_t i = tid; i < dim; i += 256) { qhi[static_cast<uint64_t>(q) * dim + i] = 0; qlo[static_cast<uint64_t>(q) * dim + i] = 0; }
-    if (tid == 0) { qscale[q] = 1.f; qinv[q] = 1.f; ebound[q] = 0.f; slack[q] = 0.f; }
+    if (tid == 0) { qscale[q] = 1.f; qinv[q] = 1.f; ebound[q] = 0.f; slack[q] = 0.f; qdelta[q] = 0.f; }
     return;
   }
   const float* src = q32 + static_cast<uint64_t>(q) * dim;
@@ -664,6 +665,7 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
   ss = (red_ss[0] + red_ss[1]) + (red_ss[2] + red_ss[3]);
   const float sq = (mx > 0.f && mx < 3.0e38f) ? mx / 16256.f : 1.f;
   const float isq = 1.0f / sq;
+  uint32_t lo2 = 0;                               // sum of lo^2 (exact: <= dim * 4096)
   for (uint32_t i = tid; i < dim; i += 256) {
     int t = static_cast<int>(rintf(src[i] * isq));
     t = t > 16256 ? 16256 : (t < -16256 ? -16256 : t);
@@ -671,8 +673,15 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
     const int lo = t - (hi << 7);                 // in [-64, 63]
     qhi[static_cast<uint64_t>(q) * dim + i] = static_cast<signed char>(hi);
     qlo[static_cast<uint64_t>(q) * dim + i] = static_cast<signed char>(lo);
+    lo2 += static_cast<uint32_t>(lo * lo);
   }
+  for (int o = 32; o > 0; o >>= 1) lo2 += __shfl_xor(lo2, o);
+  if ((tid & 63) == 0) red_lo[tid >> 6] = lo2;
+  __syncthreads();
   if (tid == 0) {
+    // what the lo plane can add to a row's filter value, in units of s_q (Cauchy-Schwarz):
+    //   |sum lo_i x_i| * scale <= ||lo|| * max_row(||x_int8|| * scale)       (filter_i8w_kernel's first stage)
+    qdelta[q] = sqrtf(static_cast<float>(red_lo[0] + red_lo[1] + red_lo[2] + red_lo[3])) * max_row_norm * 1.0001f;
     const float nrm = sqrtf(ss) * 1.0001f;
     // quantisation: |dq_i| <= 0.5 s_q (+ the rounding of q*isq: <= 2^-23 |q_i|); fp32 chains: 1e-5 ||q||
     const float eb = (0.5005f * sqrtf(static_cast<float>(dim)) * sq + 1.0e-5f * nrm) * max_row_norm * 1.001f + 1e-30f;
@@ -855,6 +864,218 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#define NVDB_MFMA_I8_ZERO_V(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b))
+#define NVDB_MFMA_I8_ACC_V(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+
+__device__ __forceinline__ int imax3(int a, int b, int c) {
+  int r;
+  asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// int8, batches > 128: "wide" two-stage build.  One wave = 64 queries, but only their HI plane is resident
+// (2 x 24 fragments = 192 AGPRs) and only the hi plane is multiplied for every tile: half the matrix work of
+// filter_i8_kernel per query.  The lo plane can change a row's filter value by at most
+//   delta_q = ||lo_q|| * max_row(||x_int8|| * scale)        (units of s_q; prep_q8_kernel)
+// so a row can only reach its threshold T if its hi-plane value reaches T - delta_q.  Per tile:
+//   stage 0 (always, ~30 vector instructions): max_r(H_r) * max_r(scale_r) * 128 >= T - delta ?   (scales > 0)
+//   stage 1 (rare): per value, 128 * H_r * scale_r >= T - delta ?
+//   stage 2 (rarer): the lo plane of that 32-query block is multiplied after all -- its fragments come from
+//            global memory (L2), the A fragments are re-read from the LDS stage, which is still intact --
+//            and the full value (128 H + L) * scale is compared with T exactly as filter_i8_kernel does.
+// The survivors logged are therefore exactly those of filter_i8_kernel, with the same filter scores.
+// Requires every row scale > 0 (the reference quantiser's max_abs/127, or 1 for an all-zero row).
+// ------------------------------------------------------------------------------------------------
+template <int DIM, int RING = 6, bool SYNC = false>
+__global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
+    const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
+    const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
+    const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qinv,
+    const float* __restrict__ qdelta, Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t* __restrict__ prog,
+    uint32_t sync_mask, uint32_t sync_lead, uint32_t* __restrict__ stage_counts) {
+  constexpr int KSTEPS = DIM / 32;
+  constexpr int ROW_BYTES = DIM;
+  constexpr int DATA_BYTES = FILTER_ROWS * ROW_BYTES;
+  constexpr int STAGE_BYTES = DATA_BYTES + 4 * 1024;
+  constexpr int PIECES = DATA_BYTES / 1024;
+  constexpr int PPW = PIECES / 4;
+  constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
+  static_assert(DIM % 256 == 0 && DIM <= 768, "row stride multiple of 256 bytes; int32 range of 128*H + L");
+  static_assert(PIECES % 4 == 0 && KSTEPS % PPW == 0 && 2 * KSTEPS <= 64, "shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, hsel = lane >> 5;
+  const uint32_t wave_gid = blockIdx.x * 4 + wave;
+
+  const uint32_t nwg = gridDim.x, b = blockIdx.x;
+  const uint32_t S = nwg / QT;
+  uint32_t stream, qt;
+  if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
+  else { qt = b % QT; stream = b / QT; }
+  const uint32_t tiles_total = (row_hi - row_lo) / FILTER_ROWS;
+  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
+  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const uint32_t NT = t_hi - t_lo;
+  if (NT == 0) return;
+
+  // stationary operand: hi plane of 64 queries (two blocks of 32), all of K, in AGPRs
+  const uint32_t qbase = qt * 256u + wave * 64u;
+  float4_t bq[2 * KSTEPS];
+#pragma unroll
+  for (int f = 0; f < 2 * KSTEPS; ++f) {
+    const int nb = f / KSTEPS, s = f % KSTEPS;
+    bq[f] = *reinterpret_cast<const float4_t*>(qhi + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 32 * s + 16 * hsel);
+  }
+#pragma unroll
+  for (int f = 0; f < 2 * KSTEPS; ++f) asm volatile("" ::"a"(bq[f]));
+  uint32_t qid[2];
+  float thr_s[2], t1q[2], inv_s[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    qid[nb] = qbase + nb * 32 + r31;
+    const bool real = qid[nb] < nq;
+    thr_s[nb] = real ? thr[qid[nb]] * qscale[qid[nb]] : __builtin_huge_valf();   // threshold in units of s_q
+    inv_s[nb] = real ? qinv[qid[nb]] : 0.f;
+    // first-stage threshold for H * scale (the factor 128 moved to this side, exactly): a little below
+    // T - delta, the margin covering the fp32 roundings of both stages' values
+    const float T = thr_s[nb];
+    t1q[nb] = real ? (T - (1.001f * qdelta[qid[nb]] + 2e-6f * fabsf(T) + 1e-5f)) * 0.0078125f : __builtin_huge_valf();
+    asm volatile("" ::"v"(thr_s[nb]), "v"(inv_s[nb]), "v"(t1q[nb]));
+  }
+  const bool wave_has_queries = qbase < nq;
+
+  uint32_t src_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const uint32_t P = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
+    const uint32_t r = P / CHUNKS_PER_ROW, cpos = P % CHUNKS_PER_ROW;
+    src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
+  }
+  const uint32_t sc_off = (lane & 7) * 16;
+  const uint32_t a_base = r31 * ROW_BYTES + ((static_cast<uint32_t>(hsel) ^ (r31 & 15u)) << 4);
+
+  const char* gbase = reinterpret_cast<const char*>(rows);
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
+  auto tile_row0 = [&](uint32_t t_rel) -> uint32_t { return row_lo + (t_lo + (t_rel < NT ? t_rel : NT - 1)) * FILTER_ROWS; };
+  auto issue_piece = [&](uint32_t row0, uint32_t buf, int i) {
+    glds16(src_off[i], gbase + static_cast<uint64_t>(row0) * ROW_BYTES, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
+  };
+  auto issue_scales = [&](uint32_t row0, uint32_t buf) {
+    glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 1024);
+  };
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(tile_row0(st), st, i);
+    issue_scales(tile_row0(st), st);
+  }
+
+  constexpr int PIECE_EVERY = KSTEPS / PPW;
+  uint32_t wcnt = 0;
+  uint32_t n_stage1 = 0, n_stage2 = 0;             // diagnostics (uniform): tiles of this wave that went past stage 0 / 1
+  Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
+
+  uint32_t sync_strikes = 0;
+  for (uint32_t t = 0; t < NT; ++t) {
+    if constexpr (SYNC) {
+      if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(prog + static_cast<uint64_t>(stream) * 8, qt, t, sync_lead, sync_strikes, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const uint32_t next_row0 = tile_row0(t + 2), next_buf = (t + 2) % FILTER_STAGES;
+    const char* stage = smem + (t % FILTER_STAGES) * STAGE_BYTES;
+    if (!wave_has_queries) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) issue_piece(next_row0, next_buf, i);
+      issue_scales(next_row0, next_buf);
+      continue;
+    }
+    auto read_a = [&](int s) -> float4_t {
+      return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256);
+    };
+    // this tile's 16 row scales for my lanes (rows (r&3) + 8*(r>>2) + 4*hsel) and their maximum
+    const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 1024);
+    float scv[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(sc_lds + 8 * j + 4 * hsel);
+      scv[4 * j] = v.x; scv[4 * j + 1] = v.y; scv[4 * j + 2] = v.z; scv[4 * j + 3] = v.w;
+    }
+    float4_t ar[RING];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(s);
+    float smax = vmax3(scv[0], scv[1], scv[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) smax = vmax3(smax, scv[r], scv[r + 1]);
+    smax = vmax3(smax, scv[15], scv[15]);
+    intx16 acc[2];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1);
+      const float4_t a = ar[s % RING];
+      if (s == 0) { NVDB_MFMA_I8_ZERO(acc[0], a, bq[0]); NVDB_MFMA_I8_ZERO(acc[1], a, bq[KSTEPS]); }
+      else { NVDB_MFMA_I8_ACC(acc[0], a, bq[s]); NVDB_MFMA_I8_ACC(acc[1], a, bq[KSTEPS + s]); }
+      if (s % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_row0, next_buf, s / PIECE_EVERY);
+      if (s == 1) issue_scales(next_row0, next_buf);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+
+    // ---- stage 0: can any of my 2 x 16 hi-plane values reach its first-stage threshold at all? --------------
+    float d0[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      int hm = imax3(acc[nb][0], acc[nb][1], acc[nb][2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) hm = imax3(hm, acc[nb][r], acc[nb][r + 1]);
+      hm = imax3(hm, acc[nb][15], 0);                                  // a non-positive maximum bounds H*scale by 0
+      d0[nb] = static_cast<float>(hm) * smax - t1q[nb];                // >= 0 iff the bound reaches the threshold
+    }
+    if (!__builtin_amdgcn_ballot_w64(vmax3(d0[0], d0[1], d0[1]) >= 0.f)) continue;
+    ++n_stage1;
+    const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      // ---- stage 1: per value ------------------------------------------------------------------------------
+      bool p = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p |= static_cast<float>(acc[nb][r]) * scv[r] >= t1q[nb];
+      if (!__builtin_amdgcn_ballot_w64(p)) continue;
+      ++n_stage2;
+      // ---- stage 2: the lo plane of this query block, fragments from global memory ---------------------------
+      const signed char* ql = qlo + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 16 * hsel;
+      intx16 lo;
+      float4_t bl[KSTEPS];
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) bl[s] = *reinterpret_cast<const float4_t*>(ql + 32 * s);   // all in flight at once
+#pragma unroll
+      for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(s);
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1);
+        const float4_t a = ar[s % RING];
+        if (s == 0) NVDB_MFMA_I8_ZERO_V(lo, a, bl[s]); else NVDB_MFMA_I8_ACC_V(lo, a, bl[s]);
+      }
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(lo));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float fv = static_cast<float>(acc[nb][r] * 128 + lo[r]) * scv[r];
+        const bool hit = fv >= thr_s[nb];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (m) {
+          const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+          if (hit && idx < FILTER_LOGCAP) mylog[idx] = Hit{fv * inv_s[nb], row0 + (r & 3) + 8 * (r >> 2) + 4 * hsel, qid[nb], 0u};
+          wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
+        }
+      }
+    }
+  }
+  if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(prog + static_cast<uint64_t>(stream) * 8 + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (stage_counts && lane == 0 && (n_stage1 | n_stage2)) { atomicAdd(stage_counts, n_stage1); atomicAdd(stage_counts + 1, n_stage2); }
+  scatter_own_log(mylog, wcnt, sa, lane);
+}
+
 // ------------------------------------------------------------------------------------------------
 // synthetic corpus generator: one wave per row (bit-identical to nvdb_synth_rows_f32 on the host
 // followed by the RNE half conversion / the reference's int8 quantiser).
@@ -924,7 +1145,10 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const void* __restric
     for (uint32_t c = lane; c < dim; c += 64) { const float v = load1<DT>(rp, c); ss = __builtin_fmaf(v, v, ss); }
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     float nrm = sqrtf(ss) * 1.0001f;
-    if constexpr (DT == DT_I8) nrm *= fabsf(scales[r]);
+    if constexpr (DT == DT_I8) {
+      nrm *= fabsf(scales[r]);
+      if (lane == 0 && !(scales[r] >= 0.f)) atomicOr(out_bits + 1, 1u);      // negative / NaN scale: filter_i8w_kernel's bound needs scale >= 0
+    }
     wmax = fmaxf(wmax, nrm);
   }
   if (lane == 0 && wmax > 0.f) atomicMax(out_bits, __builtin_bit_cast(uint32_t, wmax));

@@ -57,6 +57,9 @@ struct nvdb_hip_ctx {
   float max_norm = 0.f;
   _Float16* shadow16 = nullptr;                    // fp16 copy streamed by the MFMA filter (fp32 corpus and/or padded dim)
   uint32_t fdim = 0;                               // dim the filter kernels run at (>= dim; == dim without padding)
+  bool i8_scales_nonneg = true;                    // int8: every row scale >= 0 (the wide two-stage kernel needs it)
+  DevBuf qdelta;                                   // int8: per query, what the lo plane can add to a filter value
+  int64_t opt_i8_wide = 1;
 
   // grow-only workspace
   DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, prog;
@@ -143,10 +146,12 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   else if (c->dtype == NVDB_DTYPE_F16) row_norm_max_kernel<DT_F16><<<grid, 256, 0, c->stream>>>(c->rows, c->scales, c->n, c->dim, bits);
   else row_norm_max_kernel<DT_I8><<<grid, 256, 0, c->stream>>>(c->rows, c->scales, c->n, c->dim, bits);
   HIPCHK(c, hipGetLastError());
-  uint32_t h = 0;
-  HIPCHK(c, hipMemcpyAsync(&h, bits, 4, hipMemcpyDeviceToHost, c->stream));
+  uint32_t h = 0, hb[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(hb, bits, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  h = hb[0];
   std::memcpy(&c->max_norm, &h, 4);
+  c->i8_scales_nonneg = (hb[1] == 0);
   // Which dim do the MFMA kernels run at?  fp16 corpus with an instantiated dim: the corpus itself, no copy.
   // fp32 corpus, or fp16 with another dim <= 768: an fp16 shadow copy, rows zero-padded to the next instantiated
   // dim (skipped when values would overflow a half).  int8: its own instantiations, no shadow.
@@ -376,6 +381,41 @@ nvdb_status launch_boot_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_
 }
 
 template <int DIM>
+nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
+                                  uint32_t nq_pad, uint32_t cap) {
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * (FILTER_ROWS * DIM + 4 * 1024);
+  uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
+  if (nwg == 0) nwg = QT;
+  nvdb_status st;
+  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+  const signed char* qhi = static_cast<const signed char*>(c->q16.p);
+  const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * DIM;
+  uint32_t* counts = static_cast<uint32_t*>(c->misc.p) + 4;            // [4], [5]: tiles past stage 0 / stage 1
+  const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+#define NVDB_I8W_LAUNCH(SYNCV, PROG, MASK, LEAD)                                                                                  \
+  {                                                                                                                             \
+    const void* fn = reinterpret_cast<const void*>(filter_i8w_kernel<DIM, 6, SYNCV>);                                           \
+    if (!c->lds_attr_set.count(fn)) {                                                                                           \
+      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
+      c->lds_attr_set.insert(fn);                                                                                               \
+    }                                                                                                                           \
+    filter_i8w_kernel<DIM, 6, SYNCV><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT, \
+        static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
+        static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), PROG, MASK, LEAD, counts); \
+  }
+  if (sync) {
+    if ((st = ensure(c, c->prog, static_cast<size_t>(nwg) * 8 * 4))) return st;
+    HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, static_cast<size_t>(nwg) * 8 * 4, s));
+    NVDB_I8W_LAUNCH(true, static_cast<uint32_t*>(c->prog.p), static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead))
+  } else {
+    NVDB_I8W_LAUNCH(false, nullptr, 0u, 0u)
+  }
+#undef NVDB_I8W_LAUNCH
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+template <int DIM>
 nvdb_status launch_boot_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap) {
   constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * (FILTER_ROWS * DIM + 4 * 1024);
   const void* fn = reinterpret_cast<const void*>(filter_i8_kernel<DIM, true>);
@@ -397,6 +437,7 @@ nvdb_status launch_boot_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint
 
 nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap, uint32_t nb) {
   if (c->dtype == NVDB_DTYPE_I8) {
+    QT *= nb;                                      // the boot build is the 128-queries-per-workgroup kernel; same padded batch
     if (c->dim == 768) return launch_boot_i8_dim<768>(c, s, n0, nq, QT, cap);
     if (c->dim == 512) return launch_boot_i8_dim<512>(c, s, n0, nq, QT, cap);
     if (c->dim == 256) return launch_boot_i8_dim<256>(c, s, n0, nq, QT, cap);
@@ -408,13 +449,24 @@ nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq
   return fail(c, NVDB_ERR_UNSUPPORTED, "boot kernel: unsupported dim");
 }
 
-// NB = 32-query blocks per wave: fp16: 1 for nq <= 128 (HBM-bound regime), else 2; int8: always 1 (two planes)
-uint32_t filter_nb(const nvdb_hip_ctx* c, uint32_t nq) { return (c->dtype == NVDB_DTYPE_I8 || nq <= 128) ? 1u : 2u; }
+// int8 batches > 128: the wide two-stage kernel (64 queries per wave, hi plane resident)
+bool i8_wide(const nvdb_hip_ctx* c, uint32_t nq) { return c->dtype == NVDB_DTYPE_I8 && nq > 128 && c->opt_i8_wide && c->i8_scales_nonneg; }
+
+// NB = 32-query blocks per wave: 1 for nq <= 128 (HBM-bound regime) and for the two-plane int8 kernel, else 2
+uint32_t filter_nb(const nvdb_hip_ctx* c, uint32_t nq) {
+  if (c->dtype == NVDB_DTYPE_I8) return i8_wide(c, nq) ? 2u : 1u;
+  return nq <= 128 ? 1u : 2u;
+}
 
 nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT, uint32_t cap) {
   const uint32_t nb = filter_nb(c, nq);
   if (c->dtype == NVDB_DTYPE_I8) {
-    const uint32_t nq_pad = QT * 128u;
+    const uint32_t nq_pad = QT * 128u * nb;
+    if (nb == 2) {
+      if (c->dim == 768) return launch_filter_i8w_dim<768>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+      if (c->dim == 512) return launch_filter_i8w_dim<512>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+      if (c->dim == 256) return launch_filter_i8w_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    }
     if (c->dim == 768) return launch_filter_i8_dim<768>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->dim == 512) return launch_filter_i8_dim<512>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->dim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
@@ -474,11 +526,12 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   if ((st = ensure(c, c->qinv, nq_pad * 4))) return st;
   if ((st = ensure(c, c->ebound, nq_pad * 4))) return st;
   if ((st = ensure(c, c->slack, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->qdelta, nq_pad * 4))) return st;
   if (c->dtype == NVDB_DTYPE_I8)
     prep_q8_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->max_norm, static_cast<signed char*>(c->q16.p),
                                           static_cast<signed char*>(c->q16.p) + static_cast<size_t>(nq_pad) * c->dim,
                                           static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
-                                          static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
+                                          static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p), static_cast<float*>(c->qdelta.p));
   else
     // fp32 corpus: the shadow adds 2^-11 relative (normal halves) and <= 2^-25 absolute per element (subnormal halves)
     prep_q16_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->fdim, c->max_norm, c->dtype == NVDB_DTYPE_F32 ? FILTER_REL_F16 + 4.9e-4f : FILTER_REL_F16,
@@ -585,7 +638,7 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   free_corpus(c);
   for (DevBuf* b : {&c->q32, &c->q16, &c->qscale, &c->qinv, &c->ebound, &c->slack, &c->thr, &c->cnt, &c->overflow, &c->cand,
-                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->prog, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
+                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->prog, &c->qdelta, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& k : c->klaunch) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
@@ -699,6 +752,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "sync_lead") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "sync_lead must be >= 1"); c->opt_sync_lead = value; }
   else if (k == "sibling_sync") { c->opt_sibling_sync = value ? 1 : 0; }
   else if (k == "f32_shadow") { c->opt_f32_shadow = value ? 1 : 0; }
+  else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }
   else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
   else if (k == "refine_v2") { c->opt_refine_v2 = value ? 1 : 0; }
   else if (k == "chunk_growth") { if (value < 2 || value > 64) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be in [2,64]"); c->opt_growth = value; }
@@ -731,9 +785,10 @@ nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   HIPCHK(c, hipSetDevice(c->device));
   // caller has synchronised its stream; read the self-check words
   std::vector<uint32_t> ovf(c->last_nq);
-  uint32_t misc[4] = {0, 0, 0, 0};
+  uint32_t misc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c->last_nq) HIPCHK(c, hipMemcpy(ovf.data(), c->overflow.p, c->last_nq * 4, hipMemcpyDeviceToHost));
-  if (c->misc.p) HIPCHK(c, hipMemcpy(misc, c->misc.p, 16, hipMemcpyDeviceToHost));
+  if (c->misc.p) HIPCHK(c, hipMemcpy(misc, c->misc.p, 32, hipMemcpyDeviceToHost));
+  c->stats.i8_stage1_tiles = misc[4]; c->stats.i8_stage2_blocks = misc[5];
   uint32_t nov = 0;
   for (uint32_t v : ovf) nov += v ? 1u : 0u;
   if (misc[1]) nov = c->last_nq;                 // a wave's survivor log overflowed: which queries lost entries is unknown
@@ -788,6 +843,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     total.path = std::max(total.path, part.path);
     total.chunks += part.chunks; total.rows_scanned += part.rows_scanned; total.candidates += part.candidates;
     total.overflow_queries += part.overflow_queries; total.bound_violations += part.bound_violations;
+    total.i8_stage1_tiles += part.i8_stage1_tiles; total.i8_stage2_blocks += part.i8_stage2_blocks;
     filter_ms += part.filter_kernel_ms;
   }
   HIPCHK(c, hipEventRecord(e2, s));

@@ -49,7 +49,7 @@ class Timing(C.Structure):
 class ScanStats(C.Structure):
     _fields_ = [("path", C.c_uint32), ("chunks", C.c_uint32), ("rows_scanned", C.c_uint64), ("candidates", C.c_uint64),
                 ("overflow_queries", C.c_uint32), ("bound_violations", C.c_uint32), ("filter_kernel_ms", C.c_float),
-                ("other_kernel_ms", C.c_float)]
+                ("other_kernel_ms", C.c_float), ("i8_stage1_tiles", C.c_uint32), ("i8_stage2_blocks", C.c_uint32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

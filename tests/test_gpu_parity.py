@@ -197,6 +197,52 @@ def test_filter_path_int8_matches_oracle(ctx, oracle, nq, k, d):
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[2][0], res[2][1], k, f"filter-i8/nq{nq}")
 
 
+@pytest.mark.parametrize("nq,k,d", [(300, 10, 768), (1024, 10, 768), (130, 64, 512), (200, 5, 256)])
+def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx, oracle, nq, k, d):
+    """Batches > 128 on int8 run the 'wide' kernel: hi plane always, lo plane only for tiles whose hi-plane
+    value could reach the threshold.  It must log exactly the survivors of the two-plane kernel, so ids, score
+    bits and the number of rescored candidates are identical; both match the CPU int8 path."""
+    n = 200000 + 9
+    ctx.generate_corpus(SEED + 80, n, d, nvdb_amd.DT_I8)
+    base, scales = nvdb_amd.synth_corpus(SEED + 80, 0, n, d, nvdb_amd.DT_I8)
+    queries = nvdb_amd.synth_rows_f32(SEED + 81, 0, nq, d)
+    queries[3] *= np.float32(977.0)
+    queries[4, :7] *= np.float32(31.0)                       # heavy-tailed query: large hi-plane, small lo-plane share
+    queries[5] = np.round(queries[5] * 40) / 40              # few distinct levels
+    ctx.set_option("path", 2)
+    res, stats = {}, {}
+    for wide in (0, 1):
+        ctx.set_option("i8_wide", wide)
+        res[wide] = ctx.search_batch(queries, k)
+        stats[wide] = ctx.stats()
+        assert stats[wide]["path"] == 2 and stats[wide]["bound_violations"] == 0 and stats[wide]["overflow_queries"] == 0, stats[wide]
+    ctx.set_option("i8_wide", 1)
+    ctx.set_option("path", 0)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+    assert stats[0]["candidates"] == stats[1]["candidates"]
+    assert stats[0]["i8_stage1_tiles"] == 0 and 0 < stats[1]["i8_stage2_blocks"] <= 2 * stats[1]["i8_stage1_tiles"], stats
+    _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[1][0], res[1][1], k, f"i8-wide/nq{nq}")
+
+
+def test_int8_negative_scale_disables_the_two_stage_kernel(ctx, oracle):
+    """The quick test of the wide kernel bounds H*scale by max(H)*max(scale), which needs scale >= 0; a corpus
+    with a negative row scale (never produced by the reference quantiser) must take the two-plane kernel."""
+    n, d, nq, k = 50000, 256, 160, 10
+    base, scales = nvdb_amd.synth_corpus(SEED + 82, 0, n, d, nvdb_amd.DT_I8)
+    base, scales = base.copy(), scales.copy()
+    base[100] = -base[100]; scales[100] = -scales[100]       # same dequantised row, negative scale
+    queries = nvdb_amd.synth_rows_f32(SEED + 83, 0, nq, d)
+    queries[0] = base[100].astype(np.float32) * scales[100]
+    ctx.upload_corpus(base, po.DT_I8, scales)
+    ctx.set_option("path", 2)
+    ids, sc = ctx.search_batch(queries, k)
+    st = ctx.stats()
+    ctx.set_option("path", 0)
+    assert st["path"] == 2 and st["i8_stage1_tiles"] == 0 and st["bound_violations"] == 0, st
+    assert ids[0, 0] == 100
+    _check_against_oracle(oracle, base, po.DT_I8, scales, queries, ids, sc, k, "i8-negscale")
+
+
 def test_filter_path_scaled_and_skewed_queries(ctx, oracle):
     """Query scale must not matter (per-query power-of-two prescale), nor heavy-tailed elements."""
     n, d, nq, k = 100000, 768, 48, 10
