@@ -33,6 +33,7 @@ typedef int int4_t __attribute__((ext_vector_type(4)));
 
 constexpr int FILTER_ROWS = 32;          // corpus rows per tile (MFMA M)
 constexpr int FILTER_STAGES = 3;
+constexpr int FILTER_STAGES_I8 = 5;      // int8 stages are half the bytes: 5 stages keep 4 tiles (96 KB at d=768) in flight per workgroup
 
 // ------------------------------------------------------------------------------------------------
 // query preparation for the fp16 filter.
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
     glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 1024);
   };
 #pragma unroll
-  for (int st = 0; st < 2; ++st) {
+  for (int st = 0; st < FILTER_STAGES_I8 - 1; ++st) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) issue_piece(tile_row0(st), st, i);
     issue_scales(tile_row0(st), st);
@@ -780,10 +781,11 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
     if constexpr (SYNC) {
       if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(prog + static_cast<uint64_t>(stream) * 8, qt, t, sync_lead, sync_strikes, lane);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
+    // my pieces of tile t have landed once all but the newest FILTER_STAGES_I8-2 tiles' loads are complete
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FILTER_STAGES_I8 - 2) * (PPW + 1)) : "memory");
     __builtin_amdgcn_s_barrier();
-    const uint32_t next_row0 = tile_row0(t + 2), next_buf = (t + 2) % FILTER_STAGES;
-    const char* stage = smem + (t % FILTER_STAGES) * STAGE_BYTES;
+    const uint32_t next_row0 = tile_row0(t + FILTER_STAGES_I8 - 1), next_buf = (t + FILTER_STAGES_I8 - 1) % FILTER_STAGES_I8;
+    const char* stage = smem + (t % FILTER_STAGES_I8) * STAGE_BYTES;
     if (!wave_has_queries) {
 #pragma unroll
       for (int i = 0; i < PPW; ++i) issue_piece(next_row0, next_buf, i);
@@ -966,7 +968,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 1024);
   };
 #pragma unroll
-  for (int st = 0; st < 2; ++st) {
+  for (int st = 0; st < FILTER_STAGES_I8 - 1; ++st) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) issue_piece(tile_row0(st), st, i);
     issue_scales(tile_row0(st), st);
@@ -982,10 +984,11 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     if constexpr (SYNC) {
       if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(prog + static_cast<uint64_t>(stream) * 8, qt, t, sync_lead, sync_strikes, lane);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
+    // my pieces of tile t have landed once all but the newest FILTER_STAGES_I8-2 tiles' loads are complete
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FILTER_STAGES_I8 - 2) * (PPW + 1)) : "memory");
     __builtin_amdgcn_s_barrier();
-    const uint32_t next_row0 = tile_row0(t + 2), next_buf = (t + 2) % FILTER_STAGES;
-    const char* stage = smem + (t % FILTER_STAGES) * STAGE_BYTES;
+    const uint32_t next_row0 = tile_row0(t + FILTER_STAGES_I8 - 1), next_buf = (t + FILTER_STAGES_I8 - 1) % FILTER_STAGES_I8;
+    const char* stage = smem + (t % FILTER_STAGES_I8) * STAGE_BYTES;
     if (!wave_has_queries) {
 #pragma unroll
       for (int i = 0; i < PPW; ++i) issue_piece(next_row0, next_buf, i);

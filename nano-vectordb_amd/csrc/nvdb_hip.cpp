@@ -324,7 +324,7 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
 template <int DIM>
 nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
                                  uint32_t nq_pad, uint32_t cap) {
-  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * (FILTER_ROWS * DIM + 4 * 1024);
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * DIM + 4 * 1024);
   const void* fn = reinterpret_cast<const void*>(filter_i8_kernel<DIM>);
   if (!c->lds_attr_set.count(fn)) {
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -383,7 +383,7 @@ nvdb_status launch_boot_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_
 template <int DIM>
 nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
                                   uint32_t nq_pad, uint32_t cap) {
-  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * (FILTER_ROWS * DIM + 4 * 1024);
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * DIM + 4 * 1024);
   uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
   if (nwg == 0) nwg = QT;
   nvdb_status st;
@@ -417,7 +417,7 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
 
 template <int DIM>
 nvdb_status launch_boot_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap) {
-  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * (FILTER_ROWS * DIM + 4 * 1024);
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * DIM + 4 * 1024);
   const void* fn = reinterpret_cast<const void*>(filter_i8_kernel<DIM, true>);
   if (!c->lds_attr_set.count(fn)) {
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -859,7 +859,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
     timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
     timing->threads = 256; timing->nwarps = 4; timing->K = k;
-    timing->shmem_bytes = total.path == 2 ? static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * (c->dtype == NVDB_DTYPE_I8 ? 1 : 2) : 0;
+    timing->shmem_bytes = total.path != 2 ? 0 : c->dtype == NVDB_DTYPE_I8 ? static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * c->dim + 4096) : static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * 2;
   }
   if (total.bound_violations) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated; results were recomputed on the exact path");
   return NVDB_OK;

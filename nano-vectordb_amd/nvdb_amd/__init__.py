@@ -58,6 +58,21 @@ class ScanStats(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so.7; libnvdb_hip.so is linked
+    against /opt/rocm's, which has the same soname.  Whichever is loaded first serves both, and torch cannot
+    initialise ("No HIP GPUs are available") on top of /opt/rocm's.  bench.py and the tests share device
+    buffers and streams with torch, so when torch is installed its runtime is loaded first -- without importing
+    torch.  Stand-alone C++ users of libnvdb_hip.so (the tools in bin/) are unaffected."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Load libnvdb_hip.so; raises (never falls back) when it has not been built."""
     global _lib
@@ -66,6 +81,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C nano-vectordb_amd` "
                           "(python -c 'import __graft_entry__ as g; g.build()')")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i64, f32p = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64, C.POINTER(C.c_float)
     L.nvdb_hip_abi_version.restype = C.c_int

@@ -359,7 +359,6 @@ def test_row_sharded_search_merges_to_the_unsharded_answer(oracle):
 
 
 def test_device_merge_matches_host_merge(ctx):
-    import ctypes
     rs = np.random.RandomState(8)
     S, nq, k = 8, 50, 10
     sc = np.sort(rs.rand(S, nq, k).astype(np.float32), axis=2)[:, :, ::-1].copy()
@@ -367,26 +366,17 @@ def test_device_merge_matches_host_merge(ctx):
     sc[1] = sc[0]
     ids = (rs.permutation(S * nq * k).astype(np.uint64)).reshape(S, nq, k)
     hi, hs = nvdb_amd.merge_topk_host(ids, sc)
-    hip = ctypes.CDLL("libamdhip64.so")
-    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
-    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-    bufs = []
-
-    def dev(arr):
-        p = ctypes.c_void_p()
-        assert hip.hipMalloc(ctypes.byref(p), arr.nbytes) == 0
-        assert hip.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0
-        bufs.append(p)
-        return p
-    d_ids, d_sc = dev(ids), dev(sc)
-    oi, os_ = np.zeros((nq, k), dtype=np.uint64), np.zeros((nq, k), dtype=np.float32)
-    d_oi, d_os = dev(oi), dev(os_)
-    ctx.merge_topk_dev(d_ids, d_sc, S, nq, k, d_oi, d_os)
-    assert hip.hipDeviceSynchronize() == 0
-    assert hip.hipMemcpy(oi.ctypes.data, d_oi, oi.nbytes, 2) == 0 and hip.hipMemcpy(os_.ctypes.data, d_os, os_.nbytes, 2) == 0
+    import torch
+    dev = torch.device("cuda", 0)
+    d_ids, d_sc = torch.from_numpy(ids.view(np.int64)).to(dev), torch.from_numpy(sc).to(dev)
+    d_oi = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+    d_os = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.merge_topk_dev(d_ids.data_ptr(), d_sc.data_ptr(), S, nq, k, d_oi.data_ptr(), d_os.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    oi, os_ = d_oi.cpu().numpy().view(np.uint64), d_os.cpu().numpy()
     assert np.array_equal(oi, hi) and np.array_equal(os_.view(np.uint32), hs.view(np.uint32))
-    for p in bufs:
-        hip.hipFree(p)
 
 
 # ----------------------------------------------------------------------------- refine
