@@ -876,8 +876,8 @@ __device__ __forceinline__ int imax3(int a, int b, int c) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// int8, batches > 128: "wide" two-stage build.  One wave = 64 queries, but only their HI plane is resident
-// (2 x 24 fragments = 192 AGPRs) and only the hi plane is multiplied for every tile: half the matrix work of
+// int8 two-stage build.  One wave = NB x 32 queries (NB = 2 for batches > 128), but only their HI plane is resident
+// (NB x 24 fragments = up to 192 AGPRs) and only the hi plane is multiplied for every tile: half the matrix work of
 // filter_i8_kernel per query.  The lo plane can change a row's filter value by at most
 //   delta_q = ||lo_q|| * max_row(||x_int8|| * scale)        (units of s_q; prep_q8_kernel)
 // so a row can only reach its threshold T if its hi-plane value reaches T - delta_q.  Per tile:
@@ -889,7 +889,7 @@ __device__ __forceinline__ int imax3(int a, int b, int c) {
 // The survivors logged are therefore exactly those of filter_i8_kernel, with the same filter scores.
 // Requires every row scale > 0 (the reference quantiser's max_abs/127, or 1 for an all-zero row).
 // ------------------------------------------------------------------------------------------------
-template <int DIM, int RING = 6, bool SYNC = false>
+template <int DIM, int NB = 2, int RING = 6, bool SYNC = false>
 __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
     const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
@@ -905,6 +905,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
   static_assert(DIM % 256 == 0 && DIM <= 768, "row stride multiple of 256 bytes; int32 range of 128*H + L");
   static_assert(PIECES % 4 == 0 && KSTEPS % PPW == 0 && 2 * KSTEPS <= 64, "shape");
+  static_assert(NB == 1 || NB == 2, "one or two 32-query blocks per wave");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -922,20 +923,20 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   const uint32_t NT = t_hi - t_lo;
   if (NT == 0) return;
 
-  // stationary operand: hi plane of 64 queries (two blocks of 32), all of K, in AGPRs
-  const uint32_t qbase = qt * 256u + wave * 64u;
-  float4_t bq[2 * KSTEPS];
+  // stationary operand: hi plane of this wave's NB blocks of 32 queries, all of K, in AGPRs
+  const uint32_t qbase = qt * (128u * NB) + wave * (32u * NB);
+  float4_t bq[NB * KSTEPS];
 #pragma unroll
-  for (int f = 0; f < 2 * KSTEPS; ++f) {
+  for (int f = 0; f < NB * KSTEPS; ++f) {
     const int nb = f / KSTEPS, s = f % KSTEPS;
     bq[f] = *reinterpret_cast<const float4_t*>(qhi + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 32 * s + 16 * hsel);
   }
 #pragma unroll
-  for (int f = 0; f < 2 * KSTEPS; ++f) asm volatile("" ::"a"(bq[f]));
-  uint32_t qid[2];
-  float thr_s[2], t1q[2], inv_s[2];
+  for (int f = 0; f < NB * KSTEPS; ++f) asm volatile("" ::"a"(bq[f]));
+  uint32_t qid[NB];
+  float thr_s[NB], t1q[NB], inv_s[NB];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
+  for (int nb = 0; nb < NB; ++nb) {
     qid[nb] = qbase + nb * 32 + r31;
     const bool real = qid[nb] < nq;
     thr_s[nb] = real ? thr[qid[nb]] * qscale[qid[nb]] : __builtin_huge_valf();   // threshold in units of s_q
@@ -1013,33 +1014,37 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
 #pragma unroll
     for (int r = 3; r < 15; r += 2) smax = vmax3(smax, scv[r], scv[r + 1]);
     smax = vmax3(smax, scv[15], scv[15]);
-    intx16 acc[2];
+    intx16 acc[NB];
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1);
       const float4_t a = ar[s % RING];
-      if (s == 0) { NVDB_MFMA_I8_ZERO(acc[0], a, bq[0]); NVDB_MFMA_I8_ZERO(acc[1], a, bq[KSTEPS]); }
-      else { NVDB_MFMA_I8_ACC(acc[0], a, bq[s]); NVDB_MFMA_I8_ACC(acc[1], a, bq[KSTEPS + s]); }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if (s == 0) NVDB_MFMA_I8_ZERO(acc[nb], a, bq[nb * KSTEPS]);
+        else NVDB_MFMA_I8_ACC(acc[nb], a, bq[nb * KSTEPS + s]);
+      }
       if (s % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_row0, next_buf, s / PIECE_EVERY);
       if (s == 1) issue_scales(next_row0, next_buf);
     }
-    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+    if constexpr (NB == 2) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+    else asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]));
 
     // ---- stage 0: can any of my 2 x 16 hi-plane values reach its first-stage threshold at all? --------------
-    float d0[2];
+    float d0[NB];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       int hm = imax3(acc[nb][0], acc[nb][1], acc[nb][2]);
 #pragma unroll
       for (int r = 3; r < 15; r += 2) hm = imax3(hm, acc[nb][r], acc[nb][r + 1]);
       hm = imax3(hm, acc[nb][15], 0);                                  // a non-positive maximum bounds H*scale by 0
       d0[nb] = static_cast<float>(hm) * smax - t1q[nb];                // >= 0 iff the bound reaches the threshold
     }
-    if (!__builtin_amdgcn_ballot_w64(vmax3(d0[0], d0[1], d0[1]) >= 0.f)) continue;
+    if (!__builtin_amdgcn_ballot_w64(vmax3(d0[0], d0[NB - 1], d0[NB - 1]) >= 0.f)) continue;
     ++n_stage1;
     const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       // ---- stage 1: per value ------------------------------------------------------------------------------
       bool p = false;
 #pragma unroll

@@ -380,7 +380,7 @@ nvdb_status launch_boot_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_
   return NVDB_OK;
 }
 
-template <int DIM>
+template <int DIM, int NB>
 nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
                                   uint32_t nq_pad, uint32_t cap) {
   constexpr size_t lds = static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * DIM + 4 * 1024);
@@ -394,12 +394,12 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
 #define NVDB_I8W_LAUNCH(SYNCV, PROG, MASK, LEAD)                                                                                  \
   {                                                                                                                             \
-    const void* fn = reinterpret_cast<const void*>(filter_i8w_kernel<DIM, 6, SYNCV>);                                           \
+    const void* fn = reinterpret_cast<const void*>(filter_i8w_kernel<DIM, NB, 6, SYNCV>);                                           \
     if (!c->lds_attr_set.count(fn)) {                                                                                           \
       HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
       c->lds_attr_set.insert(fn);                                                                                               \
     }                                                                                                                           \
-    filter_i8w_kernel<DIM, 6, SYNCV><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT, \
+    filter_i8w_kernel<DIM, NB, 6, SYNCV><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT, \
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), PROG, MASK, LEAD, counts); \
   }
@@ -449,12 +449,12 @@ nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq
   return fail(c, NVDB_ERR_UNSUPPORTED, "boot kernel: unsupported dim");
 }
 
-// int8 batches > 128: the wide two-stage kernel (64 queries per wave, hi plane resident)
-bool i8_wide(const nvdb_hip_ctx* c, uint32_t nq) { return c->dtype == NVDB_DTYPE_I8 && nq > 128 && c->opt_i8_wide && c->i8_scales_nonneg; }
+// int8: the two-stage kernel (hi plane resident, lo plane on demand) unless a row scale is negative
+bool i8_two_stage(const nvdb_hip_ctx* c) { return c->dtype == NVDB_DTYPE_I8 && c->opt_i8_wide && c->i8_scales_nonneg; }
 
 // NB = 32-query blocks per wave: 1 for nq <= 128 (HBM-bound regime) and for the two-plane int8 kernel, else 2
 uint32_t filter_nb(const nvdb_hip_ctx* c, uint32_t nq) {
-  if (c->dtype == NVDB_DTYPE_I8) return i8_wide(c, nq) ? 2u : 1u;
+  if (c->dtype == NVDB_DTYPE_I8 && !i8_two_stage(c)) return 1u;
   return nq <= 128 ? 1u : 2u;
 }
 
@@ -462,10 +462,10 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
   const uint32_t nb = filter_nb(c, nq);
   if (c->dtype == NVDB_DTYPE_I8) {
     const uint32_t nq_pad = QT * 128u * nb;
-    if (nb == 2) {
-      if (c->dim == 768) return launch_filter_i8w_dim<768>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
-      if (c->dim == 512) return launch_filter_i8w_dim<512>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
-      if (c->dim == 256) return launch_filter_i8w_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (i8_two_stage(c)) {
+#define NVDB_I8W_DIM(D) if (c->dim == D) return nb == 2 ? launch_filter_i8w_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap) : launch_filter_i8w_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap)
+      NVDB_I8W_DIM(768); NVDB_I8W_DIM(512); NVDB_I8W_DIM(256);
+#undef NVDB_I8W_DIM
     }
     if (c->dim == 768) return launch_filter_i8_dim<768>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->dim == 512) return launch_filter_i8_dim<512>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
