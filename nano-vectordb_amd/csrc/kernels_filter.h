@@ -881,13 +881,11 @@ __device__ __forceinline__ int imax3(int a, int b, int c) {
 // filter_i8_kernel per query.  The lo plane can change a row's filter value by at most
 //   delta_q = ||lo_q|| * max_row(||x_int8|| * scale)        (units of s_q; prep_q8_kernel)
 // so a row can only reach its threshold T if its hi-plane value reaches T - delta_q.  Per tile:
-//   stage 0 (always, ~30 vector instructions): max_r(H_r) * max_r(scale_r) * 128 >= T - delta ?   (scales > 0)
-//   stage 1 (rare): per value, 128 * H_r * scale_r >= T - delta ?
-//   stage 2 (rarer): the lo plane of that 32-query block is multiplied after all -- its fragments come from
+//   stage 1 (always): max_r(128 * H_r * scale_r) >= T - delta ?   per 32-query block, a v_max3 tree
+//   stage 2 (rare): the lo plane of that 32-query block is multiplied after all -- its fragments come from
 //            global memory (L2), the A fragments are re-read from the LDS stage, which is still intact --
 //            and the full value (128 H + L) * scale is compared with T exactly as filter_i8_kernel does.
 // The survivors logged are therefore exactly those of filter_i8_kernel, with the same filter scores.
-// Requires every row scale > 0 (the reference quantiser's max_abs/127, or 1 for an all-zero row).
 // ------------------------------------------------------------------------------------------------
 template <int DIM, int NB = 2, int RING = 6, bool SYNC = false>
 __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
@@ -999,7 +997,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     auto read_a = [&](int s) -> float4_t {
       return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256);
     };
-    // this tile's 16 row scales for my lanes (rows (r&3) + 8*(r>>2) + 4*hsel) and their maximum
+    // this tile's 16 row scales for my lanes (rows (r&3) + 8*(r>>2) + 4*hsel)
     const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 1024);
     float scv[16];
 #pragma unroll
@@ -1010,10 +1008,6 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     float4_t ar[RING];
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(s);
-    float smax = vmax3(scv[0], scv[1], scv[2]);
-#pragma unroll
-    for (int r = 3; r < 15; r += 2) smax = vmax3(smax, scv[r], scv[r + 1]);
-    smax = vmax3(smax, scv[15], scv[15]);
     intx16 acc[NB];
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
@@ -1030,26 +1024,26 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     if constexpr (NB == 2) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
     else asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]));
 
-    // ---- stage 0: can any of my 2 x 16 hi-plane values reach its first-stage threshold at all? --------------
-    float d0[NB];
+    // ---- stage 1: can any of my NB x 16 hi-plane values H_r * scale_r reach its first-stage threshold? ----------
+    // (exact per value: cvt + mul, then a max tree per block and one compare; a cheaper bound such as
+    //  max(H) * max(scale) lets a quarter of the tiles through, and a tile costs what its slowest wave costs)
+    float d1[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      int hm = imax3(acc[nb][0], acc[nb][1], acc[nb][2]);
+      float fh[16];
 #pragma unroll
-      for (int r = 3; r < 15; r += 2) hm = imax3(hm, acc[nb][r], acc[nb][r + 1]);
-      hm = imax3(hm, acc[nb][15], 0);                                  // a non-positive maximum bounds H*scale by 0
-      d0[nb] = static_cast<float>(hm) * smax - t1q[nb];                // >= 0 iff the bound reaches the threshold
+      for (int r = 0; r < 16; ++r) fh[r] = static_cast<float>(acc[nb][r]) * scv[r];
+      float m = vmax3(fh[0], fh[1], fh[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) m = vmax3(m, fh[r], fh[r + 1]);
+      d1[nb] = vmax3(m, fh[15], fh[15]) - t1q[nb];                     // >= 0 iff some value reaches the threshold
     }
-    if (!__builtin_amdgcn_ballot_w64(vmax3(d0[0], d0[NB - 1], d0[NB - 1]) >= 0.f)) continue;
+    if (!__builtin_amdgcn_ballot_w64(vmax3(d1[0], d1[NB - 1], d1[NB - 1]) >= 0.f)) continue;
     ++n_stage1;
     const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      // ---- stage 1: per value ------------------------------------------------------------------------------
-      bool p = false;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) p |= static_cast<float>(acc[nb][r]) * scv[r] >= t1q[nb];
-      if (!__builtin_amdgcn_ballot_w64(p)) continue;
+      if (!__builtin_amdgcn_ballot_w64(d1[nb] >= 0.f)) continue;
       ++n_stage2;
       // ---- stage 2: the lo plane of this query block, fragments from global memory ---------------------------
       const signed char* ql = qlo + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 16 * hsel;
@@ -1155,7 +1149,6 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const void* __restric
     float nrm = sqrtf(ss) * 1.0001f;
     if constexpr (DT == DT_I8) {
       nrm *= fabsf(scales[r]);
-      if (lane == 0 && !(scales[r] >= 0.f)) atomicOr(out_bits + 1, 1u);      // negative / NaN scale: filter_i8w_kernel's bound needs scale >= 0
     }
     wmax = fmaxf(wmax, nrm);
   }

@@ -57,7 +57,6 @@ struct nvdb_hip_ctx {
   float max_norm = 0.f;
   _Float16* shadow16 = nullptr;                    // fp16 copy streamed by the MFMA filter (fp32 corpus and/or padded dim)
   uint32_t fdim = 0;                               // dim the filter kernels run at (>= dim; == dim without padding)
-  bool i8_scales_nonneg = true;                    // int8: every row scale >= 0 (the wide two-stage kernel needs it)
   DevBuf qdelta;                                   // int8: per query, what the lo plane can add to a filter value
   int64_t opt_i8_wide = 1;
 
@@ -151,7 +150,6 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   h = hb[0];
   std::memcpy(&c->max_norm, &h, 4);
-  c->i8_scales_nonneg = (hb[1] == 0);
   // Which dim do the MFMA kernels run at?  fp16 corpus with an instantiated dim: the corpus itself, no copy.
   // fp32 corpus, or fp16 with another dim <= 768: an fp16 shadow copy, rows zero-padded to the next instantiated
   // dim (skipped when values would overflow a half).  int8: its own instantiations, no shadow.
@@ -449,8 +447,8 @@ nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq
   return fail(c, NVDB_ERR_UNSUPPORTED, "boot kernel: unsupported dim");
 }
 
-// int8: the two-stage kernel (hi plane resident, lo plane on demand) unless a row scale is negative
-bool i8_two_stage(const nvdb_hip_ctx* c) { return c->dtype == NVDB_DTYPE_I8 && c->opt_i8_wide && c->i8_scales_nonneg; }
+// int8: the two-stage kernel (hi plane resident, lo plane on demand); option i8_wide = 0 selects the two-plane kernel
+bool i8_two_stage(const nvdb_hip_ctx* c) { return c->dtype == NVDB_DTYPE_I8 && c->opt_i8_wide; }
 
 // NB = 32-query blocks per wave: 1 for nq <= 128 (HBM-bound regime) and for the two-plane int8 kernel, else 2
 uint32_t filter_nb(const nvdb_hip_ctx* c, uint32_t nq) {

@@ -225,9 +225,9 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx, oracle, nq, k, d):
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[1][0], res[1][1], k, f"i8-wide/nq{nq}")
 
 
-def test_int8_negative_scale_disables_the_two_stage_kernel(ctx, oracle):
-    """The quick test of the wide kernel bounds H*scale by max(H)*max(scale), which needs scale >= 0; a corpus
-    with a negative row scale (never produced by the reference quantiser) must take the two-plane kernel."""
+def test_int8_two_stage_kernel_with_a_negative_row_scale(ctx, oracle):
+    """A negative row scale is never produced by the reference quantiser but is legal in the file format; both
+    stages of the kernel are sign-agnostic (per-value products; |scale| in the lo-plane bound)."""
     n, d, nq, k = 50000, 256, 160, 10
     base, scales = nvdb_amd.synth_corpus(SEED + 82, 0, n, d, nvdb_amd.DT_I8)
     base, scales = base.copy(), scales.copy()
@@ -239,7 +239,7 @@ def test_int8_negative_scale_disables_the_two_stage_kernel(ctx, oracle):
     ids, sc = ctx.search_batch(queries, k)
     st = ctx.stats()
     ctx.set_option("path", 0)
-    assert st["path"] == 2 and st["i8_stage1_tiles"] == 0 and st["bound_violations"] == 0, st
+    assert st["path"] == 2 and st["i8_stage1_tiles"] > 0 and st["bound_violations"] == 0, st
     assert ids[0, 0] == 100
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, ids, sc, k, "i8-negscale")
 
