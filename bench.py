@@ -257,7 +257,7 @@ def main():
         sec = kt["ms"] * 1e-3
         ach = kt["flops"] / sec / 1e12
         peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_I8_TOPS
-        kname = (("filter_f16_m16_kernel<768>" if B > 128 else "filter_f16_kernel<768,1>") if args.dtype == "f16" else "filter_i8_kernel<768>")
+        kname = (("filter_f16_m16_kernel<768>" if B > 128 else "filter_f16_kernel<768,1>") if args.dtype == "f16" else ("filter_i8w_kernel<768,2>" if B > 128 else "filter_i8w_kernel<768,1>"))
         gbps = kt["bytes"] / sec / 1e9
         # ridge point: intensity = 2*B*dim flop per row / row bytes  vs  peak flop / peak bytes
         hbm_bound = (2.0 * B * D / bpr) < (peak * 1e12 / (PEAK_HBM_GBPS * 1e9))
@@ -275,7 +275,7 @@ def main():
         if hbm_bound:
             out["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, **common}
         else:
-            # the int8 kernel issues TWO integer MFMAs per query block (hi/lo planes): algorithmic ops stay 2*B*N*d
+            # int8: algorithmic ops stay 2*B*N*d whatever the kernel issues (hi plane always, lo plane on demand)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if args.dtype == "f16" else "TOP/s",
                                "frac": ach / peak, **common}
     else:

@@ -65,7 +65,7 @@ struct nvdb_hip_ctx {
   DevBuf rq, rcand, rout_ids, rout_dist;           // refine
 
   // options
-  int64_t opt_path = 0, opt_chunk0 = 512, opt_cap = 0, opt_min_filter_batch = 1, opt_growth = 8;
+  int64_t opt_path = 0, opt_chunk0 = 512, opt_cap = 0, opt_min_filter_batch = 1, opt_growth = 0;   // opt_growth 0 = automatic
 
   // state of the last search
   nvdb_hip_scan_stats stats{};
@@ -544,6 +544,10 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t n_al = padded ? (n + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS : n / FILTER_ROWS * FILTER_ROWS;
   uint32_t r = 0;
   uint64_t size;
+  // chunk i covers (growth-1) x the rows seen before it.  fp16: 8 (flat between 4 and 8).  int8 batches > 128: 3 --
+  // tighter thresholds earlier mean fewer tiles for which the two-stage kernel needs the lo plane, and a tile costs
+  // what its slowest wave costs (profiles/r01d_i8_growth_sweep.txt)
+  const uint64_t growth = c->opt_growth > 0 ? static_cast<uint64_t>(c->opt_growth) : (i8_two_stage(c) && nq > 128 ? 3u : 8u);
   // T tile maxima with T >= 8k: their k-th largest is then close to the k-th best of the 32*T rows (with T == k it
   // would be the smallest tile maximum, a uselessly weak threshold)
   const uint32_t boot_rows = FILTER_ROWS * std::max<uint32_t>(64u, 8u * k_eff);
@@ -555,14 +559,14 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     if ((st = launch_boot(c, s, boot_rows, nq, QT, cap, filter_nb(c, nq)))) return st;
     fill_u32_kernel<<<(nq_pad + 255) / 256, 256, 0, s>>>(static_cast<uint32_t*>(c->cnt.p), boot_rows / FILTER_ROWS, nq);
     if ((st = launch_select(c, s, nq, cap, k_eff, slack, 2, nullptr, nullptr, 0))) return st;
-    size = static_cast<uint64_t>(boot_rows) * static_cast<uint64_t>(c->opt_growth);
+    size = static_cast<uint64_t>(boot_rows) * growth;
   } else {
     // bootstrap chunk [0,r) on the exact kernel; r is a multiple of the 32-row MFMA tile
     r = std::min<uint32_t>(n_al, (static_cast<uint32_t>(c->opt_chunk0) + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS);
     if (r > n) r = n / FILTER_ROWS * FILTER_ROWS;
     if ((st = launch_scan_exact(c, s, 0, r, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
     if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
-    size = static_cast<uint64_t>(r) * (static_cast<uint64_t>(c->opt_growth) - 1);
+    size = static_cast<uint64_t>(r) * (growth - 1);
   }
   size_t ev = 0;
   while (r < n_al) {
@@ -583,7 +587,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     c->stats.chunks++;
     c->stats.rows_scanned += static_cast<uint64_t>(hi - r) * QT;
     r = hi;
-    size = static_cast<uint64_t>(r) * (static_cast<uint64_t>(c->opt_growth) - 1);   // rows seen so far x (growth-1)
+    size = static_cast<uint64_t>(r) * (growth - 1);   // rows seen so far x (growth-1)
   }
   if (n_al < n) {   // ragged tail of an adopted corpus: exact scores, pruned by the current thresholds
     if ((st = launch_scan_exact(c, s, n_al, n, dev_q, nq, k_eff, static_cast<const float*>(c->thr.p), cap, 0))) return st;
@@ -753,7 +757,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }
   else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
   else if (k == "refine_v2") { c->opt_refine_v2 = value ? 1 : 0; }
-  else if (k == "chunk_growth") { if (value < 2 || value > 64) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be in [2,64]"); c->opt_growth = value; }
+  else if (k == "chunk_growth") { if (value != 0 && (value < 2 || value > 64)) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be 0 (automatic) or in [2,64]"); c->opt_growth = value; }
   else if (k == "min_filter_batch") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "min_filter_batch must be >= 1"); c->opt_min_filter_batch = value; }
   else return fail(c, NVDB_ERR_INVALID, "unknown option: " + k);
   return NVDB_OK;

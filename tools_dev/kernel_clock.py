@@ -11,7 +11,7 @@ secs = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
 ctx = nvdb_amd.HipContext(0)
 ctx.generate_corpus(20240613, n, 768, nvdb_amd.DT_F16)
 lib = nvdb_amd.load_library()
-for nq in (1024,):
+for nq in (1024, 512):
     q = nvdb_amd.synth_rows_f32(1, 0, nq, 768)
     ctx.set_option("path", 2); ctx.search_batch(q, 10)
     for var, name in ((0, "production loop"), (1, "no LDS-DMA"), (5, "no LDS reads"), (15, "bare MFMA stream"), (16, "bare, no epilogue"), (17, "bare, no epilogue, no barrier"), (0, "production loop")):
