@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void select_kernel(
   Cand* e = reinterpret_cast<Cand*>(smem_raw);
   __shared__ uint32_t s_keep;
   const uint32_t q = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
-  uint32_t m = cnt[q];
+  uint32_t m = (mode == 2) ? out_k : cnt[q];     // mode 2 (bootstrap): every list holds exactly out_k tile maxima
   if (m > cap) { if (tid == 0) overflow[q] = 1u; m = cap; }
   Cand* mine = cand + static_cast<uint64_t>(q) * cap;
   if (m <= 512) {
@@ -405,10 +405,13 @@ __global__ __launch_bounds__(256) void select_kernel(
 
 // one launch that resets all per-search words: list lengths, overflow flags, thresholds (-inf), self-check words
 __global__ __launch_bounds__(256) void init_search_kernel(uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow,
-                                                          float* __restrict__ thr, uint32_t* __restrict__ misc, uint32_t nq_pad) {
+                                                          float* __restrict__ thr, uint32_t* __restrict__ misc, uint32_t nq_pad,
+                                                          uint32_t* __restrict__ prog, uint32_t prog_words) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < nq_pad) { cnt[i] = 0; overflow[i] = 0; thr[i] = NEG_INF; }
   if (i < 8) misc[i] = 0;
+  // sibling-rendezvous progress counters of this search's filter launches (one region per launch): "not started"
+  for (uint32_t j = i; j < prog_words; j += gridDim.x * 256) prog[j] = 0xFFFFFFFFu;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -424,7 +427,6 @@ __global__ __launch_bounds__(256) void rescore_kernel(
   uint32_t m = cnt[q];
   if (m > cap) m = cap;
   if (m == 0) return;
-  if (threadIdx.x == 0 && total_cands) atomicAdd(total_cands, static_cast<unsigned long long>(m));
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];      // the query, padded to a multiple of 4 floats
   float* qptr = reinterpret_cast<float*>(smem_raw);
   const uint32_t qstride = (dim + 3u) & ~3u;
@@ -439,6 +441,123 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     exact_scores<DT, 1, ALIGNED>(row_ptr<DT>(rows, c.row, dim), qptr, qstride, dim, scale, sc);
     if (ebound && !(__builtin_fabsf(sc[0] - c.score) <= eb)) atomicAdd(violations, 1u);
     mine[i].score = sc[0];
+  }
+}
+
+// Same result, eight lanes per candidate: lane j of a group IS accumulator lane j of the reference kernels
+// (acc[j] += q[8i+j] * x[8i+j], i ascending -- simd_dot.cpp:31-36, 106-111; int8's two groups of 8 per iteration
+// land in the same accumulators in the same order, :164-190), then the (a0+a4)+(a1+a5) .. reduction across the
+// eight lanes (fp32 addition is commutative, so every lane ends with the same bits) and the scalar tails.
+// 32 candidates per workgroup pass instead of 256 lanes each walking a whole row alone: 12x fewer dependent
+// memory round trips for the ~12 candidates a query has left.
+template <int DT>
+__global__ __launch_bounds__(256) void rescore8_kernel(
+    const void* __restrict__ rows, const float* __restrict__ scales, uint32_t dim, const float* __restrict__ q32,
+    Cand* __restrict__ cand, const uint32_t* __restrict__ cnt, uint32_t cap, const float* __restrict__ ebound,
+    uint32_t* __restrict__ violations, unsigned long long* __restrict__ total_cands) {
+  const uint32_t q = blockIdx.x;
+  uint32_t m = cnt[q];
+  if (m > cap) m = cap;
+  if (m == 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* qptr = reinterpret_cast<float*>(smem_raw);
+  for (uint32_t j = threadIdx.x; j < dim; j += 256) qptr[j] = q32[static_cast<uint64_t>(q) * dim + j];
+  __syncthreads();
+  const float eb = ebound ? ebound[q] : 0.f;
+  Cand* mine = cand + static_cast<uint64_t>(q) * cap;
+  const uint32_t j8 = threadIdx.x & 7u, grp = threadIdx.x >> 3;
+  const uint32_t body = (DT == DT_I8) ? (dim & ~15u) : (dim & ~7u);
+  for (uint32_t base = 0; base < m; base += 32) {                 // uniform trip count: the shuffles need whole groups
+    const uint32_t i = base + grp;
+    const bool live = i < m;
+    const Cand c = live ? mine[i] : Cand{0.f, 0u};
+    const void* rp = row_ptr<DT>(rows, live ? c.row : 0u, dim);
+    float acc = 0.f;
+    uint32_t e = j8;
+#pragma unroll 48
+    for (; e < body; e += 8) acc = __builtin_fmaf(qptr[e], load1<DT>(rp, e), acc);
+    float s = acc + __shfl_xor(acc, 4);                            // a_j + a_{j^4}
+    s = s + __shfl_xor(s, 1);                                      // (s0+s1), (s2+s3)
+    s = s + __shfl_xor(s, 2);                                      // (s0+s1)+(s2+s3)
+    uint32_t t = body;
+    if (t < dim) {
+      if constexpr (DT == DT_F32) {
+        if (dim - t >= 4) {
+          for (int u = 0; u < 4; ++u) { const float p = qptr[t + u] * load1<DT>(rp, t + u); s = s + p; }
+          t += 4;
+        }
+      }
+      for (; t < dim; ++t) s = __builtin_fmaf(qptr[t], load1<DT>(rp, t), s);
+    }
+    if constexpr (DT == DT_I8) s = s * (live ? scales[c.row] : 1.f);
+    if (live && j8 == 0) {
+      if (ebound && !(__builtin_fabsf(s - c.score) <= eb)) atomicAdd(violations, 1u);
+      mine[i].score = s;
+    }
+  }
+}
+
+// The same eight-lanes-per-candidate arithmetic with the rows staged through LDS: the workgroup fetches the `cpp`
+// candidate rows of a pass with coalesced 16-byte loads (all in flight at once), then every group walks its row in
+// LDS.  Rows must be 16-byte multiples (the launcher falls back to rescore8_kernel otherwise); row slots are
+// padded by 16 bytes so that the eight groups of a wave start in different banks.
+template <int DT>
+__global__ __launch_bounds__(256) void rescore_lds_kernel(
+    const void* __restrict__ rows, const float* __restrict__ scales, uint32_t dim, const float* __restrict__ q32,
+    Cand* __restrict__ cand, const uint32_t* __restrict__ cnt, uint32_t cap, const float* __restrict__ ebound,
+    uint32_t* __restrict__ violations, unsigned long long* __restrict__ total_cands, uint32_t cpp) {
+  constexpr uint32_t BPE = (DT == DT_F32) ? 4 : (DT == DT_F16 ? 2 : 1);
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  uint32_t m = cnt[q];
+  if (m > cap) m = cap;
+  if (m == 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const uint32_t qstride = (dim + 3u) & ~3u, row_bytes = dim * BPE, slot_bytes = row_bytes + 16, cpr = row_bytes >> 4;
+  float* qptr = reinterpret_cast<float*>(smem_raw);
+  char* slots = smem_raw + qstride * 4;
+  __shared__ Cand s_cand[32];
+  for (uint32_t j = tid; j < dim; j += 256) qptr[j] = q32[static_cast<uint64_t>(q) * dim + j];
+  const float eb = ebound ? ebound[q] : 0.f;
+  Cand* mine = cand + static_cast<uint64_t>(q) * cap;
+  const uint32_t j8 = tid & 7u, grp = tid >> 3;
+  const uint32_t body = (DT == DT_I8) ? (dim & ~15u) : (dim & ~7u);
+  for (uint32_t base = 0; base < m; base += cpp) {
+    const uint32_t nrows = (m - base < cpp) ? m - base : cpp;
+    __syncthreads();                                               // previous pass has finished with the slots
+    if (tid < nrows) s_cand[tid] = mine[base + tid];
+    __syncthreads();
+    for (uint32_t c = tid; c < nrows * cpr; c += 256) {
+      const uint32_t r = c / cpr, ch = c - r * cpr;
+      const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const char*>(rows) + static_cast<uint64_t>(s_cand[r].row) * row_bytes + ch * 16);
+      *reinterpret_cast<uint4*>(slots + r * slot_bytes + ch * 16) = v;
+    }
+    __syncthreads();
+    if (grp < nrows) {                                             // whole groups of 8 lanes: the shuffles below stay inside a group
+      const Cand c = s_cand[grp];
+      const void* rp = slots + grp * slot_bytes;
+      float acc = 0.f;
+      uint32_t e = j8;
+#pragma unroll 8
+      for (; e < body; e += 8) acc = __builtin_fmaf(qptr[e], load1<DT>(rp, e), acc);
+      float s = acc + __shfl_xor(acc, 4);
+      s = s + __shfl_xor(s, 1);
+      s = s + __shfl_xor(s, 2);
+      uint32_t t = body;
+      if (t < dim) {
+        if constexpr (DT == DT_F32) {
+          if (dim - t >= 4) {
+            for (int u = 0; u < 4; ++u) { const float p = qptr[t + u] * load1<DT>(rp, t + u); s = s + p; }
+            t += 4;
+          }
+        }
+        for (; t < dim; ++t) s = __builtin_fmaf(qptr[t], load1<DT>(rp, t), s);
+      }
+      if constexpr (DT == DT_I8) s = s * scales[c.row];
+      if (j8 == 0) {
+        if (ebound && !(__builtin_fabsf(s - c.score) <= eb)) atomicAdd(violations, 1u);
+        mine[base + grp].score = s;
+      }
+    }
   }
 }
 

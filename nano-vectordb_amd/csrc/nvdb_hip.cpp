@@ -10,6 +10,7 @@
 #include "../../include/nvdb_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -59,6 +60,10 @@ struct nvdb_hip_ctx {
   uint32_t fdim = 0;                               // dim the filter kernels run at (>= dim; == dim without padding)
   DevBuf qdelta;                                   // int8: per query, what the lo plane can add to a filter value
   int64_t opt_i8_wide = 1;
+  hipEvent_t launch_e0 = nullptr, launch_e1 = nullptr;   // attached to the next filter launch (hipExtLaunchKernelGGL): its own start/stop timestamps, no extra packets
+  std::vector<hipEvent_t> kl_pool;                  // recycled events of collected launches
+  uint32_t prog_slot = 0;                          // next free region of the rendezvous counters (reset per search)
+  int64_t opt_rescore8 = 2;                        // rescore kernel: 0 lane per candidate, 1 eight lanes per candidate, 2 = 1 + rows staged through LDS
 
   // grow-only workspace
   DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, prog;
@@ -133,6 +138,8 @@ void free_corpus(nvdb_hip_ctx* c) {
 }
 
 // dims the fp16 MFMA kernels are instantiated for (multiples of 128 up to 768: the 64 queries' fragments must fit 384 registers)
+constexpr uint32_t PROG_SLOTS = 16;   // filter launches per search whose rendezvous counters the init kernel pre-clears
+
 bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128; }
 
 nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
@@ -244,14 +251,44 @@ nvdb_status launch_rescore(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uin
   const float* eb = static_cast<const float*>(c->ebound.p);
   uint32_t* viol = static_cast<uint32_t*>(c->misc.p);
   unsigned long long* tot = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->misc.p) + 8);
-  const bool al = aligned_rows(c->dtype, c->dim);
   const size_t rs_lds = static_cast<size_t>((c->dim + 3u) & ~3u) * 4;
+  const size_t row_bytes = static_cast<size_t>(c->dim) * bpe_of(c->dtype);
+  uint32_t cpp = 32;                               // candidates per pass of rescore_lds_kernel: rows + query within 60 KB of LDS
+  while (cpp > 1 && rs_lds + cpp * (row_bytes + 16) > 60 * 1024) cpp >>= 1;
+  if (c->opt_rescore8 >= 2 && (row_bytes & 15) == 0 && cpp >= 4) {
+    const size_t lds = rs_lds + cpp * (row_bytes + 16);
+    if (c->dtype == NVDB_DTYPE_F32) rescore_lds_kernel<DT_F32><<<nq, 256, lds, s>>>(c->rows, c->scales, c->dim, q32, cand, cnt, cap, eb, viol, tot, cpp);
+    else if (c->dtype == NVDB_DTYPE_F16) rescore_lds_kernel<DT_F16><<<nq, 256, lds, s>>>(c->rows, c->scales, c->dim, q32, cand, cnt, cap, eb, viol, tot, cpp);
+    else rescore_lds_kernel<DT_I8><<<nq, 256, lds, s>>>(c->rows, c->scales, c->dim, q32, cand, cnt, cap, eb, viol, tot, cpp);
+    HIPCHK(c, hipGetLastError());
+    return NVDB_OK;
+  }
+  if (c->opt_rescore8) {
+    if (c->dtype == NVDB_DTYPE_F32) rescore8_kernel<DT_F32><<<nq, 256, rs_lds, s>>>(c->rows, c->scales, c->dim, q32, cand, cnt, cap, eb, viol, tot);
+    else if (c->dtype == NVDB_DTYPE_F16) rescore8_kernel<DT_F16><<<nq, 256, rs_lds, s>>>(c->rows, c->scales, c->dim, q32, cand, cnt, cap, eb, viol, tot);
+    else rescore8_kernel<DT_I8><<<nq, 256, rs_lds, s>>>(c->rows, c->scales, c->dim, q32, cand, cnt, cap, eb, viol, tot);
+    HIPCHK(c, hipGetLastError());
+    return NVDB_OK;
+  }
+  const bool al = aligned_rows(c->dtype, c->dim);
 #define NVDB_LAUNCH_RS(DT, AL) rescore_kernel<DT, AL><<<nq, 256, rs_lds, s>>>(c->rows, c->scales, c->dim, q32, cand, cnt, cap, eb, viol, tot)
   if (c->dtype == NVDB_DTYPE_F32) { if (al) NVDB_LAUNCH_RS(DT_F32, true); else NVDB_LAUNCH_RS(DT_F32, false); }
   else if (c->dtype == NVDB_DTYPE_F16) { if (al) NVDB_LAUNCH_RS(DT_F16, true); else NVDB_LAUNCH_RS(DT_F16, false); }
   else { if (al) NVDB_LAUNCH_RS(DT_I8, true); else NVDB_LAUNCH_RS(DT_I8, false); }
 #undef NVDB_LAUNCH_RS
   HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+// rendezvous counters for the next filter launch: a region the init kernel already cleared, or (past PROG_SLOTS
+// launches in one search) a region cleared here
+nvdb_status next_prog_region(nvdb_hip_ctx* c, hipStream_t s, uint32_t nwg, uint32_t** out) {
+  const size_t region_words = static_cast<size_t>(c->num_cu) * 8;
+  if (nwg * 8u > region_words) return fail(c, NVDB_ERR_INTERNAL, "rendezvous region too small for this grid");
+  uint32_t* base = static_cast<uint32_t*>(c->prog.p) + static_cast<size_t>(c->prog_slot % PROG_SLOTS) * region_words;
+  if (c->prog_slot >= PROG_SLOTS) HIPCHK(c, hipMemsetAsync(base, 0xFF, region_words * 4, s));
+  ++c->prog_slot;
+  *out = base;
   return NVDB_OK;
 }
 
@@ -290,28 +327,28 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
     // only when the kernel's XCD-aware mapping is active (the QT workgroups of a row stream share an XCD label)
     const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
     if (sync) {
-      if ((st = ensure(c, c->prog, static_cast<size_t>(nwg) * 8 * 4))) return st;
-      HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, static_cast<size_t>(nwg) * 8 * 4, s));       // unused / not-yet-started slots read as "far ahead"
+      uint32_t* prog = nullptr;                    // unused / not-yet-started slots read 0xFFFFFFFF = "far ahead"
+      if ((st = next_prog_region(c, s, nwg, &prog))) return st;
       const void* fs = reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM, 6, true>);
       if (!c->lds_attr_set.count(fs)) {
         HIPCHK(c, hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         c->lds_attr_set.insert(fs);
       }
-      filter_f16_m16_kernel<DIM, 6, true><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
+      hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM, 6, true>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
                                                                 static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                                 static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
                                                                 static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap),
-                                                                static_cast<uint32_t*>(c->prog.p), static_cast<uint32_t>(c->opt_sync_every - 1),
+                                                                prog, static_cast<uint32_t>(c->opt_sync_every - 1),
                                                                 static_cast<uint32_t>(c->opt_sync_lead));
     } else {
-      filter_f16_m16_kernel<DIM><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
+      hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
                                                        static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                        static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
                                                        static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), nullptr, 0u, 0u);
     }
   }
   else
-    filter_f16_kernel<DIM, NB><<<nwg, 256, lds, s>>>(filter_rows_f16(c), row_lo, row_hi,
+    hipExtLaunchKernelGGL((filter_f16_kernel<DIM, NB>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
                                                      static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                      static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
                                                      static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), 0u);
@@ -336,20 +373,20 @@ nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
   const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * DIM;
   const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
   if (sync) {
-    if ((st = ensure(c, c->prog, static_cast<size_t>(nwg) * 8 * 4))) return st;
-    HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, static_cast<size_t>(nwg) * 8 * 4, s));
+    uint32_t* prog = nullptr;
+    if ((st = next_prog_region(c, s, nwg, &prog))) return st;
     const void* fs = reinterpret_cast<const void*>(filter_i8_kernel<DIM, false, 6, true>);
     if (!c->lds_attr_set.count(fs)) {
       HIPCHK(c, hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
       c->lds_attr_set.insert(fs);
     }
-    filter_i8_kernel<DIM, false, 6, true><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
+    hipExtLaunchKernelGGL((filter_i8_kernel<DIM, false, 6, true>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
                                                                 static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                                 static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
-                                                                scatter_args(c, cap), 0u, static_cast<uint32_t*>(c->prog.p),
+                                                                scatter_args(c, cap), 0u, prog,
                                                                 static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));
   } else {
-    filter_i8_kernel<DIM><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
+    hipExtLaunchKernelGGL((filter_i8_kernel<DIM>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
                                                 static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                 static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
                                                 scatter_args(c, cap), 0u, nullptr, 0u, 0u);
@@ -397,14 +434,14 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
       HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
       c->lds_attr_set.insert(fn);                                                                                               \
     }                                                                                                                           \
-    filter_i8w_kernel<DIM, NB, 6, SYNCV><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT, \
+    hipExtLaunchKernelGGL((filter_i8w_kernel<DIM, NB, 6, SYNCV>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT, \
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), PROG, MASK, LEAD, counts); \
   }
   if (sync) {
-    if ((st = ensure(c, c->prog, static_cast<size_t>(nwg) * 8 * 4))) return st;
-    HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, static_cast<size_t>(nwg) * 8 * 4, s));
-    NVDB_I8W_LAUNCH(true, static_cast<uint32_t*>(c->prog.p), static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead))
+    uint32_t* prog = nullptr;
+    if ((st = next_prog_region(c, s, nwg, &prog))) return st;
+    NVDB_I8W_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead))
   } else {
     NVDB_I8W_LAUNCH(false, nullptr, 0u, 0u)
   }
@@ -503,8 +540,13 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   if ((st = ensure(c, c->overflow, nq_pad * 4))) return st;
   if ((st = ensure(c, c->cand, static_cast<size_t>(nq) * cap * sizeof(Cand)))) return st;
   if ((st = ensure(c, c->misc, 64))) return st;
+  // one region of sibling-rendezvous counters per filter launch of this search, all reset by the init kernel
+  const uint32_t prog_words = PROG_SLOTS * static_cast<uint32_t>(c->num_cu) * 8u;
+  if ((st = ensure(c, c->prog, static_cast<size_t>(prog_words) * 4))) return st;
+  c->prog_slot = 0;
   init_search_kernel<<<(nq_pad + 255) / 256, 256, 0, s>>>(static_cast<uint32_t*>(c->cnt.p), static_cast<uint32_t*>(c->overflow.p),
-                                                          static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->misc.p), nq_pad);
+                                                          static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->misc.p), nq_pad,
+                                                          static_cast<uint32_t*>(c->prog.p), prog_words);
   HIPCHK(c, hipGetLastError());
 
   c->stats = nvdb_hip_scan_stats{};
@@ -557,8 +599,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     // thresholds from the k-th largest of the 64 tile maxima of rows [0,2048); those rows are then scanned
     // again by the normal build, so the bootstrap entries are discarded (select mode 2)
     if ((st = launch_boot(c, s, boot_rows, nq, QT, cap, filter_nb(c, nq)))) return st;
-    fill_u32_kernel<<<(nq_pad + 255) / 256, 256, 0, s>>>(static_cast<uint32_t*>(c->cnt.p), boot_rows / FILTER_ROWS, nq);
-    if ((st = launch_select(c, s, nq, cap, k_eff, slack, 2, nullptr, nullptr, 0))) return st;
+    if ((st = launch_select(c, s, nq, cap, k_eff, slack, 2, nullptr, nullptr, boot_rows / FILTER_ROWS))) return st;   // mode 2: out_k = list length
     size = static_cast<uint64_t>(boot_rows) * growth;
   } else {
     // bootstrap chunk [0,r) on the exact kernel; r is a multiple of the 32-row MFMA tile
@@ -574,15 +615,24 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     nvdb_hip_ctx::KLaunch kl{nullptr, nullptr, 0.0, 0.0};
     const bool acct = c->opt_time_kernels && c->klaunch.size() < 8192;
     if (acct) {
-      HIPCHK(c, hipEventCreate(&kl.e0)); HIPCHK(c, hipEventCreate(&kl.e1));
+      // the kernel's own start/stop timestamps (events attached to the launch itself: no barrier packets, no gaps)
+      for (hipEvent_t* e : {&kl.e0, &kl.e1}) {
+        if (!c->kl_pool.empty()) { *e = c->kl_pool.back(); c->kl_pool.pop_back(); }
+        else HIPCHK(c, hipEventCreate(e));
+      }
       kl.flops = 2.0 * nq * static_cast<double>(std::min(hi, n) - r) * c->dim;   // algorithmic: real queries, real rows
       kl.bytes = static_cast<double>(std::min(hi, n) - r) * (c->dtype == NVDB_DTYPE_I8 ? c->dim + 4.0 : c->fdim * 2.0);   // rows streamed once
-      HIPCHK(c, hipEventRecord(kl.e0, s));
+      c->launch_e0 = kl.e0; c->launch_e1 = kl.e1;
+    } else if (time_filter) {
+      c->launch_e0 = get_event(c, ev); c->launch_e1 = get_event(c, ev + 1);
     }
-    if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev), s)); }
-    if ((st = launch_filter(c, s, r, hi, nq, QT, cap))) return st;
-    if (time_filter) { HIPCHK(c, hipEventRecord(get_event(c, ev + 1), s)); c->ev_filter.emplace_back(ev, ev + 1); ev += 2; }
-    if (acct) { HIPCHK(c, hipEventRecord(kl.e1, s)); c->klaunch.push_back(kl); }
+    if (time_filter && acct) { HIPCHK(c, hipEventRecord(get_event(c, ev), s)); }
+    st = launch_filter(c, s, r, hi, nq, QT, cap);
+    c->launch_e0 = nullptr; c->launch_e1 = nullptr;
+    if (st) return st;
+    if (time_filter && acct) { HIPCHK(c, hipEventRecord(get_event(c, ev + 1), s)); }
+    if (time_filter) { c->ev_filter.emplace_back(ev, ev + 1); ev += 2; }
+    if (acct) c->klaunch.push_back(kl);
     if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
     c->stats.chunks++;
     c->stats.rows_scanned += static_cast<uint64_t>(hi - r) * QT;
@@ -644,6 +694,7 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& k : c->klaunch) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
+  for (hipEvent_t e : c->kl_pool) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -755,6 +806,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "sibling_sync") { c->opt_sibling_sync = value ? 1 : 0; }
   else if (k == "f32_shadow") { c->opt_f32_shadow = value ? 1 : 0; }
   else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }
+  else if (k == "rescore8") { c->opt_rescore8 = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
   else if (k == "refine_v2") { c->opt_refine_v2 = value ? 1 : 0; }
   else if (k == "chunk_growth") { if (value != 0 && (value < 2 || value > 64)) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be 0 (automatic) or in [2,64]"); c->opt_growth = value; }
@@ -796,7 +848,14 @@ nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   if (misc[1]) nov = c->last_nq;                 // a wave's survivor log overflowed: which queries lost entries is unknown
   c->stats.overflow_queries = nov;
   c->stats.bound_violations = misc[0];
-  unsigned long long tot; std::memcpy(&tot, &misc[2], 8);
+  // candidates that reached the rescore = the list lengths left by the last thresholding select (the final select
+  // does not touch them); summed here rather than by 1024 same-address atomics in the rescore kernel
+  unsigned long long tot = 0;
+  if (c->last_filter && c->last_nq) {
+    std::vector<uint32_t> cn(c->last_nq);
+    HIPCHK(c, hipMemcpy(cn.data(), c->cnt.p, c->last_nq * 4, hipMemcpyDeviceToHost));
+    for (uint32_t v : cn) tot += std::min(v, c->last_cap);
+  }
   c->stats.candidates = tot;
   float fms = 0.f;
   for (auto& pr : c->ev_filter) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_pool[pr.first], c->ev_pool[pr.second]) == hipSuccess) fms += ms; }
@@ -878,7 +937,7 @@ nvdb_status nvdb_hip_collect_kernel_times(nvdb_hip_ctx* c, uint32_t* launches, d
     HIPCHK(c, hipEventSynchronize(k.e1));
     HIPCHK(c, hipEventElapsedTime(&t, k.e0, k.e1));
     ms += t; fl += k.flops; by += k.bytes; ++cnt;
-    (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1);
+    c->kl_pool.push_back(k.e0); c->kl_pool.push_back(k.e1);
   }
   c->klaunch.clear();
   if (launches) *launches = cnt;
