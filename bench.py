@@ -129,6 +129,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # Everything below runs on ONE explicit stream: torch's default stream has the handle 0, which the C ABI reads as
+    # "use the context's own (non-blocking) stream" -- searches would then not be ordered with torch's copies and
+    # collectives (a stale result buffer would be gathered).
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -211,6 +215,16 @@ def main():
     if world > 1 and args.verify_merge:
         step(0)
         torch.cuda.synchronize()
+        if os.environ.get("NVDB_BENCH_DEBUG") == "1":
+            di, ds = out_ids.cpu().numpy().astype(np.uint64), out_sc.cpu().numpy()
+            hi_, hs_ = ctx.search_batch(qhost[:B], K)
+            gi = gathered.cpu().numpy()
+            g_ids = [gi[w * PACK:w * PACK + B * K * 8].view(np.uint64).reshape(B, K) for w in range(world)]
+            print(f"[debug rank {rank}] gathered part {rank} == my packed: {bool((g_ids[rank] == di).all())}; gathered q0 parts: "
+                  f"{[g[0, :3].tolist() for g in g_ids]}; merged q0 {m_ids[0, :4].tolist()}", flush=True)
+            print(f"[debug rank {rank}] device-path vs host-path on my shard: {int((di != hi_).sum())} id mismatches; "
+                  f"q0 dev {di[0, :3].tolist()} {ds[0, :3].tolist()} host {hi_[0, :3].tolist()} {hs_[0, :3].tolist()}", flush=True)
+            barrier()
         if rank == 0:
             full = nvdb_amd.HipContext(local_rank)
             full.generate_corpus(SEED, N, D, dt, row_base=0)
@@ -219,7 +233,9 @@ def main():
             mi, ms_ = m_ids.cpu().numpy().astype(np.uint64), m_sc.cpu().numpy()
             merge_check = bool(np.array_equal(mi, fi) and np.array_equal(ms_.view(np.uint32), fs.view(np.uint32)))
             if not merge_check:
-                raise SystemExit("sharded + merged result differs from the unsharded search")
+                bad = np.argwhere(mi != fi)
+                detail = "; ".join(f"q{a} #{j}: full ({fi[a, j]}, {fs[a, j]:.6f}) merged ({mi[a, j]}, {ms_[a, j]:.6f})" for a, j in bad[:6])
+                raise SystemExit(f"sharded + merged result differs from the unsharded search: {len(bad)} of {mi.size} ids; {detail}")
         barrier()
 
     # ---- timed region ---------------------------------------------------------------------------------

@@ -136,7 +136,9 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* ctx, const float* queries, uint3
                                   nvdb_hip_timing* timing);
 
 /* Same, with queries and outputs already in HBM and all work enqueued on `hip_stream`
- * (a hipStream_t; NULL = the context's own stream).  Returns after enqueueing; no host sync, so
+ * (a hipStream_t; NULL = the context's own NON-BLOCKING stream -- note that the legacy default stream also has the
+ * handle NULL: a caller whose other work is on the default stream must pass an explicit stream or synchronise the
+ * device, the context's stream is not ordered with it).  Returns after enqueueing; no host sync, so
  * overflow / bound self-checks are reported by nvdb_hip_search_check() after the caller has
  * synchronised the stream.  This is the form the multi-GPU path uses before its all-gather. */
 nvdb_status nvdb_hip_search_batch_dev(nvdb_hip_ctx* ctx, const float* dev_queries, uint32_t nq, uint32_t k,
