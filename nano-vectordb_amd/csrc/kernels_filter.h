@@ -445,7 +445,10 @@ __device__ __forceinline__ void sibling_rendezvous(uint32_t* myprog, uint32_t qt
 // loop and stores the two differences behind the progress counters, where nothing else reads them.
 // VAR (with STAMP only; results are wrong): 1 = no direct-to-LDS loads in the loop, 5 = no LDS reads (MFMA on whatever
 // the ring registers hold), 15 = neither (bare MFMA stream + barrier + epilogue), 16 = 15 without the epilogue compares, 17 = 16 without the barrier.
-template <int DIM, int RING = 6, bool SYNC = false, bool STAMP = false, int VAR = 0>
+// MB x NQB = 16-row blocks per tile x 16-query blocks per wave: 2 x 4 (32-row tiles, 64 queries per wave) for
+// DIM <= 768; 1 x 2 (16-row tiles, 32 queries per wave) for DIM up to 1536 -- the wave's B fragments are NQB*DIM/8
+// registers either way (384 at the two corners), and a stage stays 48 KB.
+template <int DIM, int RING = 6, bool SYNC = false, bool STAMP = false, int VAR = 0, int MB = 2, int NQB = 4>
 __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
     uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
@@ -453,12 +456,14 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     uint32_t sync_mask, uint32_t sync_lead) {
   constexpr int KS = DIM / 32;                     // k-steps of 32
   constexpr int ROW_BYTES = DIM * 2;
-  constexpr int STAGE_BYTES = FILTER_ROWS * ROW_BYTES;
+  constexpr int TROWS = 16 * MB;                   // corpus rows per tile
+  constexpr int STAGE_BYTES = TROWS * ROW_BYTES;
   constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / 4;
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
-  constexpr int NFRAG = 4 * KS, NFRAG_A = NFRAG < 64 ? NFRAG : 64, NFRAG_V = NFRAG - NFRAG_A;
-  constexpr int NREAD = 2 * KS;                    // A fragments per tile (2 row blocks x KS)
+  constexpr int NFRAG = NQB * KS, NFRAG_A = NFRAG < 64 ? NFRAG : 64, NFRAG_V = NFRAG - NFRAG_A;
+  constexpr int NREAD = MB * KS;                   // A fragments per tile (MB row blocks x KS)
   static_assert(DIM % 128 == 0 && PIECES % 4 == 0 && NREAD % PPW == 0, "shape");
+  static_assert((MB == 1 || MB == 2) && (NQB == 2 || NQB == 4) && NQB * KS * 4 <= 384 && STAGE_BYTES * FILTER_STAGES <= 160 * 1024, "registers / LDS");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   uint32_t stream, qt;
   if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
   else { qt = b % QT; stream = b / QT; }
-  const uint32_t tiles_total = (row_hi - row_lo) / FILTER_ROWS;
+  const uint32_t tiles_total = (row_hi - row_lo) / TROWS;
   const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
   const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
   const uint32_t NT = t_hi - t_lo;
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
 
   // B fragment f = nb*KS + s: query block nb (16 queries), k-step s; lane (x15,g4) holds
   // q16[query x15 of the block][32 s + 8 g4 .. +8]
-  const uint32_t qbase = qt * 256u + wave * 64u;
+  const uint32_t qbase = qt * (64u * NQB) + wave * (16u * NQB);
   float4_t bqa[NFRAG_A];
   float4_t bqv[NFRAG_V > 0 ? NFRAG_V : 1];
 #pragma unroll
@@ -491,10 +496,10 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   for (int f = 0; f < NFRAG_A; ++f) asm volatile("" ::"a"(bqa[f]));
 #pragma unroll
   for (int f = 0; f < NFRAG_V; ++f) asm volatile("" ::"v"(bqv[f]));
-  float thr_s[4], inv_s[4];
-  uint32_t qid[4];
+  float thr_s[NQB], inv_s[NQB];
+  uint32_t qid[NQB];
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
+  for (int nb = 0; nb < NQB; ++nb) {
     qid[nb] = qbase + nb * 16 + x15;
     const bool real = qid[nb] < nq;
     thr_s[nb] = real ? thr[qid[nb]] * qscale[qid[nb]] : __builtin_huge_valf();
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
   auto tile_ptr = [&](uint32_t t_rel) -> const char* {
     const uint32_t t = t_lo + (t_rel < NT ? t_rel : NT - 1);
-    return gbase + static_cast<uint64_t>(row_lo + t * FILTER_ROWS) * ROW_BYTES;
+    return gbase + static_cast<uint64_t>(row_lo + t * TROWS) * ROW_BYTES;
   };
   auto issue_piece = [&](const char* tile, uint32_t buf, int i) {
     glds16(src_off[i], tile, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
@@ -553,8 +558,8 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
       for (int i = 0; i < PPW; ++i) issue_piece(next_tile, next_buf, i);
       continue;
     }
-    auto read_a = [&](int u) -> float4_t {        // u = 2*s + mb
-      const int s = u >> 1, mb = u & 1;
+    auto read_a = [&](int u) -> float4_t {        // u = MB*s + mb
+      const int s = u / MB, mb = u % MB;
       return *reinterpret_cast<const float4_t*>(stage + (a16 ^ ((s & 3) << 6)) + (s >> 2) * 256 + mb * 16 * ROW_BYTES);
     };
     float4_t ar[RING];
@@ -564,14 +569,14 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     }
 #pragma unroll
     for (int u = 0; u < RING - 1; ++u) if constexpr (!NO_READ) ar[u] = read_a(u);
-    float4_t acc[2][4];
+    float4_t acc[MB][NQB];
 #pragma unroll
     for (int u = 0; u < NREAD; ++u) {
       if constexpr (!NO_READ) { if (u + RING - 1 < NREAD) ar[(u + RING - 1) % RING] = read_a(u + RING - 1); }
       const float4_t a = ar[u % RING];
-      const int s = u >> 1, mb = u & 1;
+      const int s = u / MB, mb = u % MB;
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
+      for (int nb = 0; nb < NQB; ++nb) {
         const int f = nb * KS + s;
         if (s == 0) {
           if (f < NFRAG_A) NVDB_MFMA16_ZERO_A(acc[mb][nb], a, bqa[f < NFRAG_A ? f : 0]);
@@ -583,28 +588,37 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
       }
       if constexpr (!NO_GLDS) { if (u % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_tile, next_buf, u / PIECE_EVERY); }
     }
-    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
-                                          "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+    // 32 wait states: MFMA result -> VALU read (the compiler does not see inside the asm)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NQB; ++nb) asm volatile("" : "+v"(acc[mb][nb]));
     if constexpr (NO_EPI) continue;
     // "does any of my 32 scores reach its query's threshold": a max tree per query block (v_max3_f32), one subtract
     // per block, one compare in all -- 23 vector instructions.  (32 compares into SGPR pairs + 32 s_or_b64 cost
     // ~770 cycles per tile, a quarter of the tile's MFMA time: profiles/r01d_clock_ablation.txt.)
-    float dmax[4];
+    float dmax[NQB];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
+    for (int nb = 0; nb < NQB; ++nb) {
       float m = vmax3(acc[0][nb][0], acc[0][nb][1], acc[0][nb][2]);
-      m = vmax3(m, acc[0][nb][3], acc[1][nb][0]);
-      m = vmax3(m, acc[1][nb][1], acc[1][nb][2]);
-      m = vmax3(m, acc[1][nb][3], acc[1][nb][3]);
+      if constexpr (MB == 2) {
+        m = vmax3(m, acc[0][nb][3], acc[MB - 1][nb][0]);
+        m = vmax3(m, acc[MB - 1][nb][1], acc[MB - 1][nb][2]);
+        m = vmax3(m, acc[MB - 1][nb][3], acc[MB - 1][nb][3]);
+      } else {
+        m = vmax3(m, acc[0][nb][3], acc[0][nb][3]);
+      }
       dmax[nb] = m - thr_s[nb];                      // >= 0 iff m >= thr (a difference of floats never rounds across 0)
     }
-    const bool any = vmax3(vmax3(dmax[0], dmax[1], dmax[2]), dmax[3], dmax[3]) >= 0.f;
+    const bool any = (NQB == 4 ? vmax3(vmax3(dmax[0], dmax[1], dmax[NQB / 2]), dmax[NQB - 1], dmax[NQB - 1])
+                               : vmax3(dmax[0], dmax[1], dmax[1])) >= 0.f;
     if (__builtin_amdgcn_ballot_w64(any)) {
-      const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
+      const uint32_t row0 = row_lo + (t_lo + t) * TROWS;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < NQB; ++nb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = acc[mb][nb][r];

@@ -137,10 +137,12 @@ void free_corpus(nvdb_hip_ctx* c) {
   c->rows = nullptr; c->scales = nullptr; c->owned = false; c->n = 0; c->dim = 0; c->fdim = 0; c->dtype = 0; c->max_norm = 0.f;
 }
 
-// dims the fp16 MFMA kernels are instantiated for (multiples of 128 up to 768: the 64 queries' fragments must fit 384 registers)
+// dims the fp16 MFMA kernels are instantiated for: multiples of 128 up to 768 (64 queries per wave: their fragments fill
+// 384 registers at 768), and 1024 / 1536 on the 16-row-tile build (32 queries per wave)
 constexpr uint32_t PROG_SLOTS = 16;   // filter launches per search whose rendezvous counters the init kernel pre-clears
 
-bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128; }
+bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128 || dim == 1024 || dim == 1536; }
+constexpr uint32_t F16_FILTER_MAX_DIM = 1536;
 
 nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   nvdb_status st = ensure(c, c->misc, 64);
@@ -158,10 +160,10 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   h = hb[0];
   std::memcpy(&c->max_norm, &h, 4);
   // Which dim do the MFMA kernels run at?  fp16 corpus with an instantiated dim: the corpus itself, no copy.
-  // fp32 corpus, or fp16 with another dim <= 768: an fp16 shadow copy, rows zero-padded to the next instantiated
+  // fp32 corpus, or fp16 with another dim <= 1536: an fp16 shadow copy, rows zero-padded to the next instantiated
   // dim (skipped when values would overflow a half).  int8: its own instantiations, no shadow.
   c->fdim = c->dim;
-  if (c->dtype != NVDB_DTYPE_I8 && c->dim <= 768 && !(c->dtype == NVDB_DTYPE_F16 && f16_filter_dim(c->dim)) && c->opt_f32_shadow) {
+  if (c->dtype != NVDB_DTYPE_I8 && c->dim <= F16_FILTER_MAX_DIM && !(c->dtype == NVDB_DTYPE_F16 && f16_filter_dim(c->dim)) && c->opt_f32_shadow) {
     uint32_t sdim = 128;
     while (!f16_filter_dim(sdim) || sdim < c->dim) sdim += 128;
     const size_t count = static_cast<size_t>(c->n) * sdim;
@@ -356,6 +358,36 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
   return NVDB_OK;
 }
 
+// dims 1024 / 1536: 16-row tiles, 32 queries per wave (MB = 1, NQB = 2), 128 queries per workgroup
+template <int DIM>
+nvdb_status launch_filter_k_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT, uint32_t cap) {
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * 16 * DIM * 2;
+  uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
+  if (nwg == 0) nwg = QT;
+  nvdb_status st;
+  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+  const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+  uint32_t* prog = nullptr;
+  if (sync && (st = next_prog_region(c, s, nwg, &prog))) return st;
+#define NVDB_K_LAUNCH(SYNCV)                                                                                                    \
+  {                                                                                                                             \
+    const void* fn = reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM, 6, SYNCV, false, 0, 1, 2>);                       \
+    if (!c->lds_attr_set.count(fn)) {                                                                                           \
+      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
+      c->lds_attr_set.insert(fn);                                                                                               \
+    }                                                                                                                           \
+    hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM, 6, SYNCV, false, 0, 1, 2>), dim3(nwg), dim3(256), lds, s, c->launch_e0,  \
+                          c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi, static_cast<const _Float16*>(c->q16.p), nq, QT,  \
+                          static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),                          \
+                          static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), prog,     \
+                          static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));               \
+  }
+  if (sync) NVDB_K_LAUNCH(true) else NVDB_K_LAUNCH(false)
+#undef NVDB_K_LAUNCH
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
 template <int DIM>
 nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
                                  uint32_t nq_pad, uint32_t cap) {
@@ -490,6 +522,7 @@ bool i8_two_stage(const nvdb_hip_ctx* c) { return c->dtype == NVDB_DTYPE_I8 && c
 // NB = 32-query blocks per wave: 1 for nq <= 128 (HBM-bound regime) and for the two-plane int8 kernel, else 2
 uint32_t filter_nb(const nvdb_hip_ctx* c, uint32_t nq) {
   if (c->dtype == NVDB_DTYPE_I8 && !i8_two_stage(c)) return 1u;
+  if (c->dtype != NVDB_DTYPE_I8 && c->fdim > 768) return 1u;          // 16-row-tile build: 128 queries per workgroup
   return nq <= 128 ? 1u : 2u;
 }
 
@@ -507,6 +540,8 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
     if (c->dim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 filter kernel: unsupported dim");
   }
+  if (c->fdim == 1024) return launch_filter_k_dim<1024>(c, s, row_lo, row_hi, nq, QT, cap);
+  if (c->fdim == 1536) return launch_filter_k_dim<1536>(c, s, row_lo, row_hi, nq, QT, cap);
 #define NVDB_FILTER_DIM(D) if (c->fdim == D) return nb == 1 ? launch_filter_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, cap)
   NVDB_FILTER_DIM(768); NVDB_FILTER_DIM(512); NVDB_FILTER_DIM(384); NVDB_FILTER_DIM(256); NVDB_FILTER_DIM(128);
 #undef NVDB_FILTER_DIM
@@ -525,7 +560,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t n = static_cast<uint32_t>(c->n);
   int path = force_path ? force_path : static_cast<int>(c->opt_path);
   if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
-  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 768 or an int8 corpus with dim 768/512/256");
+  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 1536 or an int8 corpus with dim 768/512/256");
 
   uint32_t cap = c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : (nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
@@ -594,7 +629,8 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // would be the smallest tile maximum, a uselessly weak threshold)
   const uint32_t boot_rows = FILTER_ROWS * std::max<uint32_t>(64u, 8u * k_eff);
   const bool mfma_boot = c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
-                         boot_rows / FILTER_ROWS <= cap;
+                         boot_rows / FILTER_ROWS <= cap &&
+                         (c->dtype == NVDB_DTYPE_I8 || c->fdim <= 768);    // no bootstrap build of the 16-row-tile kernel: exact bootstrap chunk
   if (mfma_boot) {
     // thresholds from the k-th largest of the 64 tile maxima of rows [0,2048); those rows are then scanned
     // again by the normal build, so the bootstrap entries are discarded (select mode 2)

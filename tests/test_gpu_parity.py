@@ -319,6 +319,27 @@ def test_filter_path_on_zero_padded_shadow_for_odd_dims(ctx, oracle, tag, d, nq)
     _check_against_oracle(oracle, base, po.DT_F16 if tag == "f16" else po.DT_F32, None, queries, res[2][0], res[2][1], k, f"pad/{tag}/d{d}")
 
 
+@pytest.mark.parametrize("tag,d,nq", [("f16", 1536, 300), ("f16", 1024, 64), ("f16", 1000, 130), ("f32", 1536, 40), ("f16", 1280, 33)])
+def test_filter_path_for_dims_up_to_1536(ctx, oracle, tag, d, nq):
+    """768 < dim <= 1536: the 16-row-tile build of the fp16 kernel (32 queries per wave; dims other than 1024 / 1536
+    through the zero-padded shadow).  Same exact rescore, so ids and score bits match the CPU path."""
+    n, k = 60000 + 5, 10
+    dt = nvdb_amd.DT_F16 if tag == "f16" else nvdb_amd.DT_F32
+    ctx.generate_corpus(SEED + 90, n, d, dt)
+    base, _ = nvdb_amd.synth_corpus(SEED + 90, 0, n, d, dt)
+    queries = nvdb_amd.synth_rows_f32(SEED + 91, 0, nq, d)
+    queries[1] = oracle.f16_to_f32(base[4321]) if tag == "f16" else base[4321]
+    res = {}
+    for path in (1, 2):
+        ctx.set_option("path", path)
+        res[path] = ctx.search_batch(queries, k)
+        st = ctx.stats()
+        assert st["path"] == path and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    ctx.set_option("path", 0)
+    assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1].view(np.uint32), res[2][1].view(np.uint32))
+    _check_against_oracle(oracle, base, po.DT_F16 if tag == "f16" else po.DT_F32, None, queries, res[2][0], res[2][1], k, f"bigdim/{tag}/d{d}")
+
+
 def test_overflow_falls_back_to_exact_path(ctx, oracle):
     """Adversarial order (rows sorted by score ascending for the query) overflows the candidate
     lists; the library must notice and still return the exact answer."""
