@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
 // into the wave's own LDS slot, so that no ordinary global load -- whose compiler-inserted vmcnt wait
 // would drain the stream -- is needed in the loop).
 // ================================================================================================
-__global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim,
+__global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim, uint32_t sdim,
                                                       float max_row_norm, signed char* __restrict__ qhi,
                                                       signed char* __restrict__ qlo, float* __restrict__ qscale,
                                                       float* __restrict__ qinv, float* __restrict__ ebound,
@@ -665,8 +665,9 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
   __shared__ float red_max[4], red_ss[4];
   __shared__ uint32_t red_lo[4];
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  // sdim >= dim: row stride of the two planes = the (zero-padded) dim the filter kernel is instantiated for
   if (q >= nq) {
-    for (uint32_t i = tid; i < dim; i += 256) { qhi[static_cast<uint64_t>(q) * dim + i] = 0; qlo[static_cast<uint64_t>(q) * dim + i] = 0; }
+    for (uint32_t i = tid; i < sdim; i += 256) { qhi[static_cast<uint64_t>(q) * sdim + i] = 0; qlo[static_cast<uint64_t>(q) * sdim + i] = 0; }
     if (tid == 0) { qscale[q] = 1.f; qinv[q] = 1.f; ebound[q] = 0.f; slack[q] = 0.f; qdelta[q] = 0.f; }
     return;
   }
@@ -686,10 +687,11 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
     t = t > 16256 ? 16256 : (t < -16256 ? -16256 : t);
     const int hi = (t + 64) >> 7;                 // floor((t+64)/128), arithmetic shift
     const int lo = t - (hi << 7);                 // in [-64, 63]
-    qhi[static_cast<uint64_t>(q) * dim + i] = static_cast<signed char>(hi);
-    qlo[static_cast<uint64_t>(q) * dim + i] = static_cast<signed char>(lo);
+    qhi[static_cast<uint64_t>(q) * sdim + i] = static_cast<signed char>(hi);
+    qlo[static_cast<uint64_t>(q) * sdim + i] = static_cast<signed char>(lo);
     lo2 += static_cast<uint32_t>(lo * lo);
   }
+  for (uint32_t i = dim + tid; i < sdim; i += 256) { qhi[static_cast<uint64_t>(q) * sdim + i] = 0; qlo[static_cast<uint64_t>(q) * sdim + i] = 0; }
   for (int o = 32; o > 0; o >>= 1) lo2 += __shfl_xor(lo2, o);
   if ((tid & 63) == 0) red_lo[tid >> 6] = lo2;
   __syncthreads();
@@ -1147,6 +1149,18 @@ __global__ __launch_bounds__(256) void shadow_f16_kernel(const SrcT* __restrict_
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(maxabs_bits, __builtin_bit_cast(uint32_t, mx));
+}
+
+// int8 corpus whose dim is not 256 / 512 / 768: copy with rows zero-padded to sdim bytes (the swizzled LDS image
+// needs a row stride that is a multiple of 256 bytes); 16 source bytes per thread where alignment allows
+__global__ __launch_bounds__(256) void shadow_i8_kernel(const signed char* __restrict__ src, signed char* __restrict__ dst, size_t n,
+                                                        uint32_t dim, uint32_t sdim) {
+  const size_t count = n * sdim;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<size_t>(gridDim.x) * 256) {
+    const size_t r = i / sdim;
+    const uint32_t c = static_cast<uint32_t>(i - r * sdim);
+    dst[i] = c < dim ? src[r * dim + c] : static_cast<signed char>(0);
+  }
 }
 
 // max over rows of the (dequantised) L2 norm, slightly inflated; result as float bits via atomicMax

@@ -56,6 +56,8 @@ struct nvdb_hip_ctx {
   uint32_t dim = 0, dtype = 0;
   uint64_t row_base = 0;
   float max_norm = 0.f;
+  signed char* shadow8 = nullptr;                  // int8 corpus with a dim the kernels are not instantiated for: rows zero-padded to fdim
+  float* shadow8_scales = nullptr;                 // ... and its scales in a buffer padded to whole tiles
   _Float16* shadow16 = nullptr;                    // fp16 copy streamed by the MFMA filter (fp32 corpus and/or padded dim)
   uint32_t fdim = 0;                               // dim the filter kernels run at (>= dim; == dim without padding)
   DevBuf qdelta;                                   // int8: per query, what the lo plane can add to a filter value
@@ -134,6 +136,8 @@ void free_corpus(nvdb_hip_ctx* c) {
     if (c->scales) (void)hipFree(c->scales);
   }
   if (c->shadow16) { (void)hipFree(c->shadow16); c->shadow16 = nullptr; }
+  if (c->shadow8) { (void)hipFree(c->shadow8); c->shadow8 = nullptr; }
+  if (c->shadow8_scales) { (void)hipFree(c->shadow8_scales); c->shadow8_scales = nullptr; }
   c->rows = nullptr; c->scales = nullptr; c->owned = false; c->n = 0; c->dim = 0; c->fdim = 0; c->dtype = 0; c->max_norm = 0.f;
 }
 
@@ -143,6 +147,7 @@ constexpr uint32_t PROG_SLOTS = 16;   // filter launches per search whose rendez
 
 bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128 || dim == 1024 || dim == 1536; }
 constexpr uint32_t F16_FILTER_MAX_DIM = 1536;
+bool i8_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 256; }   // int8 rows: stride % 256 == 0
 
 nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   nvdb_status st = ensure(c, c->misc, 64);
@@ -179,6 +184,21 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
     float maxabs; std::memcpy(&maxabs, &h, 4);
     if (!(maxabs < 60000.f)) { (void)hipFree(c->shadow16); c->shadow16 = nullptr; }
     else c->fdim = sdim;
+  }
+  if (c->dtype == NVDB_DTYPE_I8 && c->dim <= 768 && !i8_filter_dim(c->dim) && c->opt_f32_shadow) {
+    uint32_t sdim = 256;
+    while (sdim < c->dim) sdim += 256;
+    const size_t count = static_cast<size_t>(c->n) * sdim, pad = static_cast<size_t>(FILTER_ROWS) * sdim + 4096;
+    const size_t n_pad = (static_cast<size_t>(c->n) + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS + FILTER_ROWS;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow8), count + pad));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow8_scales), n_pad * 4));
+    HIPCHK(c, hipMemsetAsync(c->shadow8 + count, 0, pad, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->shadow8_scales, 0, n_pad * 4, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->shadow8_scales, c->scales, static_cast<size_t>(c->n) * 4, hipMemcpyDeviceToDevice, c->stream));
+    shadow_i8_kernel<<<4096, 256, 0, c->stream>>>(static_cast<const signed char*>(c->rows), c->shadow8, c->n, c->dim, sdim);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->fdim = sdim;
   }
   return NVDB_OK;
 }
@@ -300,6 +320,8 @@ ScatterArgs scatter_args(nvdb_hip_ctx* c, uint32_t cap) {
 }
 
 // what the fp16 MFMA kernels stream: the corpus itself, or the fp16 shadow of an fp32 corpus
+const signed char* filter_rows_i8(const nvdb_hip_ctx* c) { return c->shadow8 ? c->shadow8 : static_cast<const signed char*>(c->rows); }
+const float* filter_scales_i8(const nvdb_hip_ctx* c) { return c->shadow8 ? c->shadow8_scales : c->scales; }
 const _Float16* filter_rows_f16(const nvdb_hip_ctx* c) {
   return c->shadow16 ? c->shadow16 : static_cast<const _Float16*>(c->rows);
 }
@@ -307,7 +329,7 @@ const _Float16* filter_rows_f16(const nvdb_hip_ctx* c) {
 bool filter_supported(const nvdb_hip_ctx* c) {
   if (c->dtype == NVDB_DTYPE_F16) return f16_filter_dim(c->dim) || c->shadow16 != nullptr;
   if (c->dtype == NVDB_DTYPE_F32) return c->shadow16 != nullptr;
-  if (c->dtype == NVDB_DTYPE_I8) return c->dim == 768 || c->dim == 512 || c->dim == 256;   // int8 rows: stride % 256 == 0
+  if (c->dtype == NVDB_DTYPE_I8) return i8_filter_dim(c->dim) || c->shadow8 != nullptr;
   return false;
 }
 
@@ -412,13 +434,13 @@ nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
       HIPCHK(c, hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
       c->lds_attr_set.insert(fs);
     }
-    hipExtLaunchKernelGGL((filter_i8_kernel<DIM, false, 6, true>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
+    hipExtLaunchKernelGGL((filter_i8_kernel<DIM, false, 6, true>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT,
                                                                 static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                                 static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
                                                                 scatter_args(c, cap), 0u, prog,
                                                                 static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));
   } else {
-    hipExtLaunchKernelGGL((filter_i8_kernel<DIM>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT,
+    hipExtLaunchKernelGGL((filter_i8_kernel<DIM>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT,
                                                 static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                 static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
                                                 scatter_args(c, cap), 0u, nullptr, 0u, 0u);
@@ -466,7 +488,7 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
       HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
       c->lds_attr_set.insert(fn);                                                                                               \
     }                                                                                                                           \
-    hipExtLaunchKernelGGL((filter_i8w_kernel<DIM, NB, 6, SYNCV>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, static_cast<const signed char*>(c->rows), c->scales, row_lo, row_hi, qhi, qlo, nq, QT, \
+    hipExtLaunchKernelGGL((filter_i8w_kernel<DIM, NB, 6, SYNCV>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), PROG, MASK, LEAD, counts); \
   }
@@ -494,7 +516,7 @@ nvdb_status launch_boot_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint
   if (nwg == 0) nwg = QT;
   const signed char* qhi = static_cast<const signed char*>(c->q16.p);
   const signed char* qlo = qhi + static_cast<size_t>(QT) * 128u * DIM;
-  filter_i8_kernel<DIM, true><<<nwg, 256, lds, s>>>(static_cast<const signed char*>(c->rows), c->scales, 0, n0, qhi, qlo, nq, QT,
+  filter_i8_kernel<DIM, true><<<nwg, 256, lds, s>>>(filter_rows_i8(c), filter_scales_i8(c), 0, n0, qhi, qlo, nq, QT,
                                                     static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                     static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->cand.p),
                                                     scatter_args(c, cap), cap, nullptr, 0u, 0u);
@@ -505,9 +527,9 @@ nvdb_status launch_boot_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint
 nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap, uint32_t nb) {
   if (c->dtype == NVDB_DTYPE_I8) {
     QT *= nb;                                      // the boot build is the 128-queries-per-workgroup kernel; same padded batch
-    if (c->dim == 768) return launch_boot_i8_dim<768>(c, s, n0, nq, QT, cap);
-    if (c->dim == 512) return launch_boot_i8_dim<512>(c, s, n0, nq, QT, cap);
-    if (c->dim == 256) return launch_boot_i8_dim<256>(c, s, n0, nq, QT, cap);
+    if (c->fdim == 768) return launch_boot_i8_dim<768>(c, s, n0, nq, QT, cap);
+    if (c->fdim == 512) return launch_boot_i8_dim<512>(c, s, n0, nq, QT, cap);
+    if (c->fdim == 256) return launch_boot_i8_dim<256>(c, s, n0, nq, QT, cap);
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 boot kernel: unsupported dim");
   }
 #define NVDB_BOOT_DIM(D) if (c->fdim == D) return nb == 1 ? launch_boot_dim<D, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<D, 2>(c, s, n0, nq, QT, cap)
@@ -531,13 +553,13 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
   if (c->dtype == NVDB_DTYPE_I8) {
     const uint32_t nq_pad = QT * 128u * nb;
     if (i8_two_stage(c)) {
-#define NVDB_I8W_DIM(D) if (c->dim == D) return nb == 2 ? launch_filter_i8w_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap) : launch_filter_i8w_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap)
+#define NVDB_I8W_DIM(D) if (c->fdim == D) return nb == 2 ? launch_filter_i8w_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap) : launch_filter_i8w_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap)
       NVDB_I8W_DIM(768); NVDB_I8W_DIM(512); NVDB_I8W_DIM(256);
 #undef NVDB_I8W_DIM
     }
-    if (c->dim == 768) return launch_filter_i8_dim<768>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
-    if (c->dim == 512) return launch_filter_i8_dim<512>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
-    if (c->dim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->fdim == 768) return launch_filter_i8_dim<768>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->fdim == 512) return launch_filter_i8_dim<512>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->fdim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 filter kernel: unsupported dim");
   }
   if (c->fdim == 1024) return launch_filter_k_dim<1024>(c, s, row_lo, row_hi, nq, QT, cap);
@@ -560,7 +582,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t n = static_cast<uint32_t>(c->n);
   int path = force_path ? force_path : static_cast<int>(c->opt_path);
   if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
-  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 1536 or an int8 corpus with dim 768/512/256");
+  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 1536 or an int8 corpus with dim <= 768");
 
   uint32_t cap = c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : (nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
@@ -603,8 +625,8 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   if ((st = ensure(c, c->slack, nq_pad * 4))) return st;
   if ((st = ensure(c, c->qdelta, nq_pad * 4))) return st;
   if (c->dtype == NVDB_DTYPE_I8)
-    prep_q8_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->max_norm, static_cast<signed char*>(c->q16.p),
-                                          static_cast<signed char*>(c->q16.p) + static_cast<size_t>(nq_pad) * c->dim,
+    prep_q8_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->fdim, c->max_norm, static_cast<signed char*>(c->q16.p),
+                                          static_cast<signed char*>(c->q16.p) + static_cast<size_t>(nq_pad) * c->fdim,
                                           static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
                                           static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p), static_cast<float*>(c->qdelta.p));
   else
@@ -617,7 +639,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const float* slack = static_cast<const float*>(c->slack.p);
   // Whole tiles: a corpus this library allocated is zero-padded to a multiple of 32 rows (the padded rows are
   // dropped when the wave files its survivors); for an adopted corpus the ragged tail goes to the exact kernel.
-  const bool padded = c->owned || c->shadow16 != nullptr;          // a shadow copy is always ours, hence padded
+  const bool padded = c->owned || c->shadow16 != nullptr || c->shadow8 != nullptr;          // a shadow copy is always ours, hence padded
   const uint32_t n_al = padded ? (n + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS : n / FILTER_ROWS * FILTER_ROWS;
   uint32_t r = 0;
   uint64_t size;
@@ -657,7 +679,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
         else HIPCHK(c, hipEventCreate(e));
       }
       kl.flops = 2.0 * nq * static_cast<double>(std::min(hi, n) - r) * c->dim;   // algorithmic: real queries, real rows
-      kl.bytes = static_cast<double>(std::min(hi, n) - r) * (c->dtype == NVDB_DTYPE_I8 ? c->dim + 4.0 : c->fdim * 2.0);   // rows streamed once
+      kl.bytes = static_cast<double>(std::min(hi, n) - r) * (c->dtype == NVDB_DTYPE_I8 ? c->fdim + 4.0 : c->fdim * 2.0);   // rows streamed once
       c->launch_e0 = kl.e0; c->launch_e1 = kl.e1;
     } else if (time_filter) {
       c->launch_e0 = get_event(c, ev); c->launch_e1 = get_event(c, ev + 1);
@@ -956,7 +978,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
     timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
     timing->threads = 256; timing->nwarps = 4; timing->K = k;
-    timing->shmem_bytes = total.path != 2 ? 0 : c->dtype == NVDB_DTYPE_I8 ? static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * c->dim + 4096) : static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * 2;
+    timing->shmem_bytes = total.path != 2 ? 0 : c->dtype == NVDB_DTYPE_I8 ? static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * c->fdim + 4096) : static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * 2;
   }
   if (total.bound_violations) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated; results were recomputed on the exact path");
   return NVDB_OK;

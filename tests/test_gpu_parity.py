@@ -225,6 +225,26 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx, oracle, nq, k, d):
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[1][0], res[1][1], k, f"i8-wide/nq{nq}")
 
 
+@pytest.mark.parametrize("d,nq,k", [(384, 200, 10), (384, 48, 10), (100, 70, 5), (640, 300, 10)])
+def test_int8_other_dims_through_the_zero_padded_shadow(ctx, oracle, d, nq, k):
+    """int8 corpora whose dim is not 256/512/768 (384 is the reference's own data dimension): the filter streams a
+    copy with rows zero-padded to the next multiple of 256 bytes; the rescore reads the original rows."""
+    n = 90000 + 3
+    ctx.generate_corpus(SEED + 84, n, d, nvdb_amd.DT_I8)
+    base, scales = nvdb_amd.synth_corpus(SEED + 84, 0, n, d, nvdb_amd.DT_I8)
+    queries = nvdb_amd.synth_rows_f32(SEED + 85, 0, nq, d)
+    queries[2] = base[5555].astype(np.float32) * scales[5555]
+    res = {}
+    for path in (1, 2):
+        ctx.set_option("path", path)
+        res[path] = ctx.search_batch(queries, k)
+        st = ctx.stats()
+        assert st["path"] == path and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    ctx.set_option("path", 0)
+    assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1].view(np.uint32), res[2][1].view(np.uint32))
+    _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[2][0], res[2][1], k, f"i8-pad/d{d}")
+
+
 def test_int8_two_stage_kernel_with_a_negative_row_scale(ctx, oracle):
     """A negative row scale is never produced by the reference quantiser but is legal in the file format; both
     stages of the kernel are sign-agnostic (per-value products; |scale| in the lo-plane bound)."""
