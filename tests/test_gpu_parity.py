@@ -522,6 +522,38 @@ def test_full_size_10M_properties(oracle, dtype, tag):
 
 
 # ----------------------------------------------------------------------------- device-buffer entry points (torch as plumbing)
+@pytest.mark.parametrize("tag,nq", [("f16", 1500), ("i8", 2000), ("f16", 1025)])
+def test_device_api_with_more_than_1024_queries_in_one_call(oracle, tag, nq):
+    """nvdb_hip_search_batch_dev takes up to 2048 queries per call (the host API splits at 1024): more query tiles
+    than the XCD-aware grid / sibling rendezvous cover, so the kernels fall back to the plain block mapping."""
+    import torch
+    n, d, k = 120000 + 17, 768, 10
+    dt = nvdb_amd.DT_F16 if tag == "f16" else nvdb_amd.DT_I8
+    c = nvdb_amd.HipContext(0)
+    c.generate_corpus(SEED + 95, n, d, dt)
+    base, scales = nvdb_amd.synth_corpus(SEED + 95, 0, n, d, dt)
+    queries = nvdb_amd.synth_rows_f32(SEED + 96, 0, nq, d)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        t_q = torch.from_numpy(queries).to(dev)
+        t_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        t_sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        c.set_option("path", 2)
+        c.search_batch_dev(t_q.data_ptr(), nq, k, t_ids.data_ptr(), t_sc.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    s = c.search_check()
+    assert s["path"] == 2 and s["bound_violations"] == 0 and s["overflow_queries"] == 0, s
+    ids, sc = t_ids.cpu().numpy().astype(np.uint64), t_sc.cpu().numpy()
+    sub = np.r_[0:40, nq - 40:nq]                              # the oracle on a subset keeps the test short
+    oid, osc = oracle.flat_topk(base, po.DT_F16 if tag == "f16" else po.DT_I8, queries[sub], k, scales)
+    assert np.array_equal(ids[sub], oid) and np.array_equal(sc[sub].view(np.uint32), osc.view(np.uint32))
+    c.set_option("path", 1)                                    # and the whole batch against the exact kernel
+    hi_, hs_ = c.search_batch(queries, k)
+    assert np.array_equal(ids, hi_) and np.array_equal(sc.view(np.uint32), hs_.view(np.uint32))
+    c.close()
+
+
 @pytest.mark.parametrize("tag", ["f16", "i8", "f32"])
 def test_adopted_corpus_and_device_buffers(oracle, tag):
     """nvdb_hip_adopt_corpus (corpus already in HBM, not owned, NOT padded -> ragged tail on the exact kernel) and
