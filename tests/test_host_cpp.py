@@ -95,6 +95,37 @@ def test_nvdb_bench_rejects_bad_input(files, built):
     assert r.returncode == 3 and "Unknown mode" in r.stderr
 
 
+def test_cpu_modes_under_address_and_ub_sanitizers(files, golden, tmp_path):
+    """The host layer (loader, SIMD dots, top-k buffers, the four CPU threadings, converters, gt writer) built with
+    -fsanitize=address,undefined must run clean and still produce the reference's bytes.  CPU build only."""
+    pkg = os.path.join(ROOT, "nano-vectordb_amd")
+    subprocess.check_call(["make", "-C", pkg, "asan", "-j4"], stdout=subprocess.DEVNULL)
+    abin = os.path.join(pkg, "bin_asan")
+    env = dict(os.environ, OMP_NUM_THREADS="2", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+
+    def arun(tool, *args, extra=None):
+        e = dict(env); e.update(extra or {})
+        r = subprocess.run([os.path.join(abin, tool), *map(str, args)], capture_output=True, text=True, env=e)
+        assert r.returncode == 0, f"{tool} {args}: rc={r.returncode}\n{r.stderr[-2000:]}"
+        assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]
+        return r.stdout
+    b16, b8 = str(tmp_path / "b16.vecbin"), str(tmp_path / "b8.vecbin")
+    arun("nvdb_convert_f16", files["b32"], b16)
+    arun("nvdb_quantize_i8", files["b32"], b8)
+    assert open(b16, "rb").read() == open(files["b16"], "rb").read() and open(b8, "rb").read() == open(files["b8"], "rb").read()
+    assert arun("nvdb_search", files["b32"], files["q"], 10) == bytes(golden["main768_search_stdout"]).decode()
+    sinks = set()
+    for mode, extra in (("st", []), ("omp", ["2"]), ("async", ["3"]), ("pool", ["3"]), ("omp", ["2", "1", "4", "512", "0"]), ("pool", ["2", "1", "4", "512", "0"])):
+        for base in (files["b16"], b8):
+            out = arun("nvdb_bench", base, files["q"], 10, mode, *extra)
+            sinks.add((base == b8, re.search(r"sink=(\S+)", out).group(1)))
+    assert len(sinks) == 2                                      # one sink per dtype, whatever the threading
+    gt = str(tmp_path / "gt.gtbin")
+    for mode in ("st", "pool"):
+        arun("nvdb_gt_build", files["b16"], files["q"], 10, gt, extra={"GT_MODE": mode})
+        assert np.array_equal(po.read_gtbin(gt)[0], golden["main768_gtbin_f16_ids"])
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_gpu_modes_of_the_tools(files, golden):
