@@ -1,20 +1,26 @@
-// kernels_filter.h -- the hot kernel: MFMA filter scan of the fp16 / int8 corpus (gfx950, CDNA4).
+// kernels_filter.h -- the hot kernels: MFMA filter scan of the fp16 / int8 corpus (gfx950, CDNA4).
 //
-// Dataflow (DESIGN.md "filter kernel"):
-//   * a workgroup = 4 wavefronts = one per SIMD, 512-register budget each; it owns 256 queries
-//     (64 per wave).  Every wave keeps its 64 queries' B-operand fragments for the WHOLE K = DIM
-//     in registers (DIM/2 VGPRs) for the lifetime of the kernel -- queries are the stationary
-//     operand, they never touch LDS and are read from memory exactly once per launch.
-//   * the corpus is the streamed operand: tiles of 32 rows x DIM (48 KB at DIM=768, fp16) go
-//     HBM -> LDS with direct-to-LDS loads (global_load_lds_dwordx4, 1 KB per wave-instruction),
-//     three stages deep, one s_barrier per tile, counted vmcnt so two tiles stay in flight.
-//   * per tile and wave: DIM/16 ds_read_b128 (A fragment, XOR-swizzled image, conflict-free) feed
-//     2*DIM/16 v_mfma_f32_32x32x16_f16 (two 32-query blocks share each A fragment).
-//   * epilogue: accumulator D[row][query] has the query on the lane, so the per-query threshold
-//     is one VGPR; 32 compares per tile; survivors (rare) are appended to the query's candidate
-//     list with a global atomic.  Nothing else is written: the B x N score matrix never exists.
+// Dataflow ("The filter kernel -- CDNA4 mapping"):
+//   * a workgroup = 4 wavefronts = one per SIMD, 512-register budget each.  Every wave keeps the B-operand
+//     fragments of its queries for the WHOLE K = DIM in registers for the lifetime of the kernel (384 registers:
+//     64 queries at DIM <= 768, 32 at DIM <= 1536) -- queries are the stationary operand, they never touch LDS and
+//     are read from memory once per launch.
+//   * the corpus is the streamed operand: tiles of 32 (or 16) rows x DIM, 48 KB, go HBM -> LDS with direct-to-LDS
+//     loads (global_load_lds_dwordx4, 1 KB per wave-instruction), three stages deep, one s_barrier per tile,
+//     counted vmcnt so two tiles stay in flight; the workgroups that stream the same rows keep together through a
+//     sibling rendezvous so that the XCD's L2 serves all but one of them.
+//   * per tile and wave: ds_read_b128 A fragments (XOR-swizzled image, conflict-free) feed the MFMAs from inline
+//     asm (B operands read in place from AGPRs); the accumulator has the query on the lane, so a threshold is one
+//     VGPR and "does anything reach it" is a v_max3 tree + one compare.
+//   * survivors (rare) are logged per wave with plain stores and filed under their queries when the wave has
+//     finished its stream (scatter_own_log).  Nothing else is written: the B x N score matrix never exists.
 //
-// The MFMA result is only a FILTER: |filter - reference score| <= ebound[q] (prep kernel), every
+// Kernels: filter_f16_m16_kernel (production fp16, v_mfma_f32_16x16x32_f16; MB/NQB pick the tile shape),
+// filter_f16_kernel (32x32x16 build: batches <= 128, the bootstrap build VAR 7, timing ablations),
+// filter_i8w_kernel (int8 two-stage: hi plane always, lo plane on demand), filter_i8_kernel (int8 two-plane:
+// bootstrap build, A/B reference), prep_q16 / prep_q8 (query scaling, error bounds), shadow / generator / norm kernels.
+//
+// The MFMA result is only a FILTER: |filter - reference score| <= ebound[q] (prep kernels), every
 // survivor is re-scored in the reference's exact fp32 order afterwards (kernels_exact.h).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     }
     if (__builtin_amdgcn_ballot_w64(any)) {
       // rare path: log the survivors in this wave's own region (plain 16-byte stores, no atomics,
-      // nothing to wait for); scatter_hits_kernel files them under their queries afterwards.
+      // nothing to wait for); scatter_own_log files them under their queries when the stream is done.
       const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
