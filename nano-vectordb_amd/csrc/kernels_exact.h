@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     float sc[1];
     const float scale = (DT == DT_I8) ? scales[c.row] : 1.f;
     exact_scores<DT, 1, ALIGNED>(row_ptr<DT>(rows, c.row, dim), qptr, qstride, dim, scale, sc);
-    if (ebound && !(__builtin_fabsf(sc[0] - c.score) <= eb)) atomicAdd(violations, 1u);
+    if (ebound && eb >= 0.f && !(__builtin_fabsf(sc[0] - c.score) <= eb)) atomicAdd(violations, 1u);
     mine[i].score = sc[0];
   }
 }
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void rescore8_kernel(
     }
     if constexpr (DT == DT_I8) s = s * (live ? scales[c.row] : 1.f);
     if (live && j8 == 0) {
-      if (ebound && !(__builtin_fabsf(s - c.score) <= eb)) atomicAdd(violations, 1u);
+      if (ebound && eb >= 0.f && !(__builtin_fabsf(s - c.score) <= eb)) atomicAdd(violations, 1u);
       mine[i].score = s;
     }
   }
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void rescore_lds_kernel(
       }
       if constexpr (DT == DT_I8) s = s * scales[c.row];
       if (j8 == 0) {
-        if (ebound && !(__builtin_fabsf(s - c.score) <= eb)) atomicAdd(violations, 1u);
+        if (ebound && eb >= 0.f && !(__builtin_fabsf(s - c.score) <= eb)) atomicAdd(violations, 1u);
         mine[base + grp].score = s;
       }
     }

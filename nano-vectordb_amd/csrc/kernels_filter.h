@@ -51,7 +51,7 @@ constexpr int FILTER_STAGES_I8 = 5;      // int8 stages are half the bytes: 5 st
 // grid = nq_pad (multiple of 256), block = 256.  Pad queries get zeros.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim, uint32_t sdim,
-                                                       float max_row_norm, float rel, float abs_per_norm, _Float16* __restrict__ q16,
+                                                       float max_row_norm, float rel, float abs_per_norm, uint32_t* __restrict__ overflow, _Float16* __restrict__ q16,
                                                        float* __restrict__ qscale, float* __restrict__ qinv,
                                                        float* __restrict__ ebound, float* __restrict__ slack) {
   __shared__ float red_max[4], red_ss[4];
@@ -83,6 +83,9 @@ __global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__
     // abs_per_norm: absolute rounding of the corpus side (fp16 shadow of an fp32 corpus: subnormal halves)
     const float eb = rel * nrm * max_row_norm + abs_per_norm * nrm + 1e-30f;
     qscale[q] = sc; qinv[q] = ldexpf(1.f, -e); ebound[q] = eb; slack[q] = 2.f * eb;
+    // a query with a NaN / infinite element (or a norm beyond fp32) has no usable bound: flag it like a list overflow,
+    // the host redoes its sub-batch on the exact path, whose comparisons treat such scores as the CPU path does
+    if (!(ss < 3.0e38f)) { overflow[q] = 1u; ebound[q] = -1.f; }     // negative bound = "do not self-check this query"
   }
 }
 
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
                                                       float max_row_norm, signed char* __restrict__ qhi,
                                                       signed char* __restrict__ qlo, float* __restrict__ qscale,
                                                       float* __restrict__ qinv, float* __restrict__ ebound,
-                                                      float* __restrict__ slack, float* __restrict__ qdelta) {
+                                                      float* __restrict__ slack, float* __restrict__ qdelta, uint32_t* __restrict__ overflow) {
   __shared__ float red_max[4], red_ss[4];
   __shared__ uint32_t red_lo[4];
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
@@ -705,10 +708,12 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
     // what the lo plane can add to a row's filter value, in units of s_q (Cauchy-Schwarz):
     //   |sum lo_i x_i| * scale <= ||lo|| * max_row(||x_int8|| * scale)       (filter_i8w_kernel's first stage)
     qdelta[q] = sqrtf(static_cast<float>(red_lo[0] + red_lo[1] + red_lo[2] + red_lo[3])) * max_row_norm * 1.0001f;
+
     const float nrm = sqrtf(ss) * 1.0001f;
     // quantisation: |dq_i| <= 0.5 s_q (+ the rounding of q*isq: <= 2^-23 |q_i|); fp32 chains: 1e-5 ||q||
     const float eb = (0.5005f * sqrtf(static_cast<float>(dim)) * sq + 1.0e-5f * nrm) * max_row_norm * 1.001f + 1e-30f;
     qscale[q] = isq; qinv[q] = sq; ebound[q] = eb; slack[q] = 2.f * eb;
+    if (!(ss < 3.0e38f)) { overflow[q] = 1u; ebound[q] = -1.f; }     // NaN / infinite query: exact path (see prep_q16_kernel)
   }
 }
 

@@ -628,11 +628,13 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     prep_q8_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->fdim, c->max_norm, static_cast<signed char*>(c->q16.p),
                                           static_cast<signed char*>(c->q16.p) + static_cast<size_t>(nq_pad) * c->fdim,
                                           static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
-                                          static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p), static_cast<float*>(c->qdelta.p));
+                                          static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p), static_cast<float*>(c->qdelta.p),
+                                          static_cast<uint32_t*>(c->overflow.p));
   else
     // fp32 corpus: the shadow adds 2^-11 relative (normal halves) and <= 2^-25 absolute per element (subnormal halves)
     prep_q16_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->fdim, c->max_norm, c->dtype == NVDB_DTYPE_F32 ? FILTER_REL_F16 + 4.9e-4f : FILTER_REL_F16,
-                                           c->dtype == NVDB_DTYPE_F32 ? 3.0e-8f * std::sqrt(static_cast<float>(c->dim)) : 0.f, static_cast<_Float16*>(c->q16.p),
+                                           c->dtype == NVDB_DTYPE_F32 ? 3.0e-8f * std::sqrt(static_cast<float>(c->dim)) : 0.f, static_cast<uint32_t*>(c->overflow.p),
+                                           static_cast<_Float16*>(c->q16.p),
                                            static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
                                            static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p));
   HIPCHK(c, hipGetLastError());

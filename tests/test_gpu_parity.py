@@ -360,6 +360,30 @@ def test_filter_path_for_dims_up_to_1536(ctx, oracle, tag, d, nq):
     _check_against_oracle(oracle, base, po.DT_F16 if tag == "f16" else po.DT_F32, None, queries, res[2][0], res[2][1], k, f"bigdim/{tag}/d{d}")
 
 
+@pytest.mark.parametrize("tag", ["f16", "i8"])
+def test_non_finite_queries_take_the_exact_path(ctx, oracle, tag):
+    """A query with a NaN or an infinite element has no usable filter bound: it is flagged like a list overflow and
+    its sub-batch is redone on the exact kernel.  The finite queries of the batch still match the CPU path."""
+    n, d, nq, k = 40000, 768, 24, 10
+    dt = nvdb_amd.DT_F16 if tag == "f16" else nvdb_amd.DT_I8
+    ctx.generate_corpus(SEED + 97, n, d, dt)
+    base, scales = nvdb_amd.synth_corpus(SEED + 97, 0, n, d, dt)
+    queries = nvdb_amd.synth_rows_f32(SEED + 98, 0, nq, d)
+    queries[3, 5] = np.nan
+    queries[7, 100] = np.inf
+    queries[9] *= np.float32(3e37)                            # finite elements, norm^2 beyond fp32
+    ctx.set_option("path", 1)
+    ei, es = ctx.search_batch(queries, k)
+    ctx.set_option("path", 2)
+    fi, fs = ctx.search_batch(queries, k)
+    st = ctx.stats()
+    ctx.set_option("path", 0)
+    assert st["overflow_queries"] >= 3 and st["bound_violations"] == 0, st      # flagged -> sub-batch redone on the exact path
+    assert np.array_equal(fi, ei) and np.array_equal(fs.view(np.uint32), es.view(np.uint32))
+    good = [i for i in range(nq) if i not in (3, 7, 9)]
+    _check_against_oracle(oracle, base, po.DT_F16 if tag == "f16" else po.DT_I8, scales, queries[good], fi[good], fs[good], k, "nonfinite/rest")
+
+
 def test_overflow_falls_back_to_exact_path(ctx, oracle):
     """Adversarial order (rows sorted by score ascending for the query) overflows the candidate
     lists; the library must notice and still return the exact answer."""
