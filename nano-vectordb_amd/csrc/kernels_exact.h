@@ -303,13 +303,15 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(
 __global__ __launch_bounds__(256) void select_kernel(
     Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t k, const float* __restrict__ slack,
     float* __restrict__ thr, uint32_t* __restrict__ overflow, int mode, uint64_t row_base,
-    unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, uint32_t out_k) {
+    unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, uint32_t out_k, uint32_t* __restrict__ any_overflow) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Cand* e = reinterpret_cast<Cand*>(smem_raw);
   __shared__ uint32_t s_keep;
   const uint32_t q = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
   uint32_t m = (mode == 2) ? out_k : cnt[q];     // mode 2 (bootstrap): every list holds exactly out_k tile maxima
   if (m > cap) { if (tid == 0) overflow[q] = 1u; m = cap; }
+  // final select: fold the per-query flags (list overflow, non-finite query) into one word the host can read alone
+  if (mode == 1 && tid == 0 && overflow[q]) atomicOr(any_overflow, 1u);
   Cand* mine = cand + static_cast<uint64_t>(q) * cap;
   if (m <= 512) {
     // short list (the usual case): rank every entry against all others with broadcast LDS reads -- one pass,

@@ -62,6 +62,9 @@ struct nvdb_hip_ctx {
   uint32_t fdim = 0;                               // dim the filter kernels run at (>= dim; == dim without padding)
   DevBuf qdelta;                                   // int8: per query, what the lo plane can add to a filter value
   int64_t opt_i8_wide = 1;
+  void* pinned = nullptr;                           // pinned host staging of small calls: status words, results, queries
+  size_t pinned_bytes = 0;
+  bool stats_lazy = false;                          // stats.candidates not read back yet (nvdb_hip_get_stats does it)
   hipEvent_t launch_e0 = nullptr, launch_e1 = nullptr;   // attached to the next filter launch (hipExtLaunchKernelGGL): its own start/stop timestamps, no extra packets
   std::vector<hipEvent_t> kl_pool;                  // recycled events of collected launches
   uint32_t prog_slot = 0;                          // next free region of the rendezvous counters (reset per search)
@@ -262,7 +265,8 @@ nvdb_status launch_select(nvdb_hip_ctx* c, hipStream_t s, uint32_t nq, uint32_t 
   }
   select_kernel<<<nq, 256, cap * sizeof(Cand), s>>>(static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap, k, slack,
                                                    static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->overflow.p), mode,
-                                                   c->row_base, reinterpret_cast<unsigned long long*>(out_ids), out_scores, out_k);
+                                                   c->row_base, reinterpret_cast<unsigned long long*>(out_ids), out_scores, out_k,
+                                                   static_cast<uint32_t*>(c->misc.p) + 6);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -755,6 +759,7 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& k : c->klaunch) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
   for (hipEvent_t e : c->kl_pool) (void)hipEventDestroy(e);
+  if (c->pinned) (void)hipHostFree(c->pinned);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -940,6 +945,71 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
   if ((st = ensure(c, c->out_ids, static_cast<size_t>(nq) * k * 8))) return st;
   if ((st = ensure(c, c->out_scores, static_cast<size_t>(nq) * k * 4))) return st;
   hipEvent_t e0 = get_event(c, 60), e1 = get_event(c, 61), e2 = get_event(c, 62), e3 = get_event(c, 63);
+  c->stats_lazy = false;
+  if (nq <= 1024) {
+    // One sub-batch: everything the host needs comes back in ONE synchronisation through pinned staging -- the
+    // self-check words (32 B), ids and scores -- instead of five small pageable copies of ~20 us each (a third of
+    // a single-query search at N = 1M).  Small query blocks go up through the same staging buffer.
+    const size_t ob_ids = static_cast<size_t>(nq) * k * 8, ob_sc = static_cast<size_t>(nq) * k * 4;
+    const size_t q_stage = qbytes <= 64 * 1024 ? qbytes : 0;
+    const size_t need = 64 + ob_ids + ob_sc + q_stage;
+    if (c->pinned_bytes < need) {
+      if (c->pinned) (void)hipHostFree(c->pinned);
+      c->pinned = nullptr; c->pinned_bytes = 0;
+      HIPCHK(c, hipHostMalloc(&c->pinned, need + need / 2, hipHostMallocDefault));
+      c->pinned_bytes = need + need / 2;
+    }
+    char* pin = static_cast<char*>(c->pinned);
+    uint32_t* pin_status = reinterpret_cast<uint32_t*>(pin);
+    char* pin_ids = pin + 64; char* pin_sc = pin_ids + ob_ids; char* pin_q = pin_sc + ob_sc;
+    HIPCHK(c, hipEventRecord(e0, s));
+    HIPCHK(c, hipMemsetAsync(static_cast<char*>(c->q32.p) + qbytes, 0, 8 * static_cast<size_t>(c->dim) * 4, s));
+    if (q_stage) { std::memcpy(pin_q, queries, qbytes); HIPCHK(c, hipMemcpyAsync(c->q32.p, pin_q, qbytes, hipMemcpyHostToDevice, s)); }
+    else HIPCHK(c, hipMemcpyAsync(c->q32.p, queries, qbytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipEventRecord(e1, s));
+    const float* dq = static_cast<const float*>(c->q32.p);
+    uint64_t* oi = static_cast<uint64_t*>(c->out_ids.p);
+    float* os = static_cast<float*>(c->out_scores.p);
+    if ((st = search_core(c, s, dq, nq, k, oi, os, 0, timing != nullptr))) return st;
+    HIPCHK(c, hipEventRecord(e2, s));
+    auto fetch = [&]() -> nvdb_status {
+      HIPCHK(c, hipMemcpyAsync(pin_status, c->misc.p, 32, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipMemcpyAsync(pin_ids, oi, ob_ids, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipMemcpyAsync(pin_sc, os, ob_sc, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipEventRecord(e3, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      return NVDB_OK;
+    };
+    if ((st = fetch())) return st;
+    nvdb_hip_scan_stats part = c->stats;
+    if (pin_status[0] | pin_status[1] | pin_status[6]) {
+      // self-check tripped (rare): exact counts, then redo the batch on the always-correct exact path
+      nvdb_status chk = nvdb_hip_search_check(c, &part);
+      if (chk == NVDB_ERR_HIP) return chk;
+      if ((st = search_core(c, s, dq, nq, k, oi, os, 1, false))) return st;
+      if ((st = fetch())) return st;
+      c->stats = part;
+    } else {
+      part.i8_stage1_tiles = pin_status[4]; part.i8_stage2_blocks = pin_status[5];
+      float fms = 0.f;
+      for (auto& pr : c->ev_filter) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_pool[pr.first], c->ev_pool[pr.second]) == hipSuccess) fms += ms; }
+      part.filter_kernel_ms = fms;
+      c->stats = part;
+      c->stats_lazy = c->last_filter;                 // candidates: read back on demand
+    }
+    std::memcpy(out_ids, pin_ids, ob_ids);
+    std::memcpy(out_scores, pin_sc, ob_sc);
+    if (timing) {
+      (void)hipEventElapsedTime(&timing->h2d_ms, e0, e1);
+      (void)hipEventElapsedTime(&timing->kernel_ms, e1, e2);
+      (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
+      timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
+      timing->threads = 256; timing->nwarps = 4; timing->K = k;
+      timing->shmem_bytes = part.path != 2 ? 0 : c->dtype == NVDB_DTYPE_I8 ? static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * c->fdim + 4096) : static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * 2;
+    }
+    if (part.bound_violations) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated; results were recomputed on the exact path");
+    return NVDB_OK;
+  }
   HIPCHK(c, hipEventRecord(e0, s));
   HIPCHK(c, hipMemsetAsync(static_cast<char*>(c->q32.p) + qbytes, 0, 8 * static_cast<size_t>(c->dim) * 4, s));
   HIPCHK(c, hipMemcpyAsync(c->q32.p, queries, qbytes, hipMemcpyHostToDevice, s));
@@ -1135,6 +1205,17 @@ nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* c, int variant, uint32_t nq, floa
 
 nvdb_status nvdb_hip_get_stats(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   if (!c || !stats) return NVDB_ERR_INVALID;
+  if (c->stats_lazy) {                             // the small-call path skips this read-back; do it now
+    c->stats_lazy = false;
+    unsigned long long tot = 0;
+    if (c->last_nq) {
+      HIPCHK(c, hipSetDevice(c->device));
+      std::vector<uint32_t> cn(c->last_nq);
+      HIPCHK(c, hipMemcpy(cn.data(), c->cnt.p, c->last_nq * 4, hipMemcpyDeviceToHost));
+      for (uint32_t v : cn) tot += std::min(v, c->last_cap);
+    }
+    c->stats.candidates = tot;
+  }
   *stats = c->stats;
   return NVDB_OK;
 }
