@@ -353,7 +353,7 @@ def main():
                                              "algorithmic_TOPs": 2.0 * bb * N * D / el / 1e12,
                                              "two_stage": {"tiles_past_quick_test": timed_passes.last_stats.get("i8_stage1_tiles"),
                                                            "lo_plane_blocks": timed_passes.last_stats.get("i8_stage2_blocks"),
-                                                           "wave_tiles": (N // 32) * ((bb + 63) // 64 if bb > 128 else (bb + 31) // 32)}}
+                                                           "wave_tiles": (N // 64) * ((bb + 63) // 64 if bb > 128 else (bb + 31) // 32)}}
             # recall@10 of the int8 corpus against the fp32 corpus' exact top-10 (500K-row prefix, 64 queries)
             nr = min(N, 500_000)
             c32 = nvdb_amd.HipContext(local_rank)

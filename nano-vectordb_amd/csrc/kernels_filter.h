@@ -914,7 +914,9 @@ __device__ __forceinline__ int imax3(int a, int b, int c) {
 //            and the full value (128 H + L) * scale is compared with T exactly as filter_i8_kernel does.
 // The survivors logged are therefore exactly those of filter_i8_kernel, with the same filter scores.
 // ------------------------------------------------------------------------------------------------
-template <int DIM, int NB = 2, int RING = 6, bool SYNC = false>
+// MB = 32-row blocks per tile: 2 -> 64-row tiles (a 52 KB stage, three of them) halve the per-tile costs (barrier,
+// loop-top scalar code, rendezvous, MFMA drain) per row; 1 -> 32-row tiles, five stages (debug / A-B only).
+template <int DIM, int NB = 2, int RING = 6, bool SYNC = false, int MB = 2>
 __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
     const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
@@ -923,14 +925,17 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     uint32_t sync_mask, uint32_t sync_lead, uint32_t* __restrict__ stage_counts) {
   constexpr int KSTEPS = DIM / 32;
   constexpr int ROW_BYTES = DIM;
-  constexpr int DATA_BYTES = FILTER_ROWS * ROW_BYTES;
+  constexpr int TROWS = FILTER_ROWS * MB;          // corpus rows per tile
+  constexpr int NSTAGE = MB == 2 ? 3 : FILTER_STAGES_I8;
+  constexpr int DATA_BYTES = TROWS * ROW_BYTES;
   constexpr int STAGE_BYTES = DATA_BYTES + 4 * 1024;
   constexpr int PIECES = DATA_BYTES / 1024;
   constexpr int PPW = PIECES / 4;
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
   static_assert(DIM % 256 == 0 && DIM <= 768, "row stride multiple of 256 bytes; int32 range of 128*H + L");
-  static_assert(PIECES % 4 == 0 && KSTEPS % PPW == 0 && 2 * KSTEPS <= 64, "shape");
+  static_assert(PIECES % 4 == 0 && (MB * KSTEPS) % PPW == 0 && 2 * KSTEPS <= 64 && KSTEPS % 2 == 0, "shape");
   static_assert(NB == 1 || NB == 2, "one or two 32-query blocks per wave");
+  static_assert((MB == 1 || MB == 2) && NSTAGE * STAGE_BYTES <= 160 * 1024 && (NSTAGE - 2) * (PPW + 1) < 64, "LDS / vmcnt range");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -942,7 +947,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   uint32_t stream, qt;
   if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
   else { qt = b % QT; stream = b / QT; }
-  const uint32_t tiles_total = (row_hi - row_lo) / FILTER_ROWS;
+  const uint32_t tiles_total = (row_hi - row_lo) / TROWS;
   const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
   const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
   const uint32_t NT = t_hi - t_lo;
@@ -981,26 +986,25 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     const uint32_t r = P / CHUNKS_PER_ROW, cpos = P % CHUNKS_PER_ROW;
     src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
   }
-  const uint32_t sc_off = (lane & 7) * 16;
+  const uint32_t sc_off = (lane & (8 * MB - 1)) * 16;   // TROWS row scales = 128 * MB bytes; the other lanes re-load the same chunks
   const uint32_t a_base = r31 * ROW_BYTES + ((static_cast<uint32_t>(hsel) ^ (r31 & 15u)) << 4);
 
   const char* gbase = reinterpret_cast<const char*>(rows);
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
-  auto tile_row0 = [&](uint32_t t_rel) -> uint32_t { return row_lo + (t_lo + (t_rel < NT ? t_rel : NT - 1)) * FILTER_ROWS; };
+  auto tile_row0 = [&](uint32_t t_rel) -> uint32_t { return row_lo + (t_lo + (t_rel < NT ? t_rel : NT - 1)) * TROWS; };
   auto issue_piece = [&](uint32_t row0, uint32_t buf, int i) {
     glds16(src_off[i], gbase + static_cast<uint64_t>(row0) * ROW_BYTES, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
   };
-  auto issue_scales = [&](uint32_t row0, uint32_t buf) {
-    glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 1024);
+  auto issue_scales = [&](uint32_t row0, uint32_t buf) {         // only the lanes that carry distinct bytes take part
+    if (lane < 8 * MB) glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 1024);
   };
 #pragma unroll
-  for (int st = 0; st < FILTER_STAGES_I8 - 1; ++st) {
+  for (int st = 0; st < NSTAGE - 1; ++st) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) issue_piece(tile_row0(st), st, i);
     issue_scales(tile_row0(st), st);
   }
 
-  constexpr int PIECE_EVERY = KSTEPS / PPW;
   uint32_t wcnt = 0;
   uint32_t n_stage1 = 0, n_stage2 = 0;             // diagnostics (uniform): tiles of this wave that went past stage 0 / 1
   Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
@@ -1010,95 +1014,113 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     if constexpr (SYNC) {
       if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(prog + static_cast<uint64_t>(stream) * 8, qt, t, sync_lead, sync_strikes, lane);
     }
-    // my pieces of tile t have landed once all but the newest FILTER_STAGES_I8-2 tiles' loads are complete
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FILTER_STAGES_I8 - 2) * (PPW + 1)) : "memory");
+    // my pieces of tile t have landed once all but the newest NSTAGE-2 tiles' loads are complete
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (PPW + 1)) : "memory");
     __builtin_amdgcn_s_barrier();
-    const uint32_t next_row0 = tile_row0(t + FILTER_STAGES_I8 - 1), next_buf = (t + FILTER_STAGES_I8 - 1) % FILTER_STAGES_I8;
-    const char* stage = smem + (t % FILTER_STAGES_I8) * STAGE_BYTES;
+    const uint32_t next_row0 = tile_row0(t + NSTAGE - 1), next_buf = (t + NSTAGE - 1) % NSTAGE;
+    const char* stage = smem + (t % NSTAGE) * STAGE_BYTES;
     if (!wave_has_queries) {
 #pragma unroll
       for (int i = 0; i < PPW; ++i) issue_piece(next_row0, next_buf, i);
       issue_scales(next_row0, next_buf);
       continue;
     }
-    auto read_a = [&](int s) -> float4_t {
-      return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256);
+    auto read_a = [&](int u) -> float4_t {        // u = MB*s + mb: k-step s of row block mb
+      const int s = u / MB, mb = u % MB;
+      return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256 + mb * FILTER_ROWS * ROW_BYTES);
     };
-    // this tile's 16 row scales for my lanes (rows (r&3) + 8*(r>>2) + 4*hsel)
+    // this tile's 16 row scales per row block for my lanes (rows 32*mb + (r&3) + 8*(r>>2) + 4*hsel)
     const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 1024);
-    float scv[16];
+    float scv[MB][16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(sc_lds + 8 * j + 4 * hsel);
-      scv[4 * j] = v.x; scv[4 * j + 1] = v.y; scv[4 * j + 2] = v.z; scv[4 * j + 3] = v.w;
-    }
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(sc_lds + 32 * mb + 8 * j + 4 * hsel);
+        scv[mb][4 * j] = v.x; scv[mb][4 * j + 1] = v.y; scv[mb][4 * j + 2] = v.z; scv[mb][4 * j + 3] = v.w;
+      }
+    constexpr int NREAD = MB * KSTEPS;
     float4_t ar[RING];
 #pragma unroll
-    for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(s);
-    intx16 acc[NB];
+    for (int u = 0; u < RING - 1; ++u) ar[u] = read_a(u);
+    intx16 acc[MB][NB];
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1);
-      const float4_t a = ar[s % RING];
+    for (int u = 0; u < NREAD; ++u) {
+      if (u + RING - 1 < NREAD) ar[(u + RING - 1) % RING] = read_a(u + RING - 1);
+      const float4_t a = ar[u % RING];
+      const int s = u / MB, mb = u % MB;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        if (s == 0) NVDB_MFMA_I8_ZERO(acc[nb], a, bq[nb * KSTEPS]);
-        else NVDB_MFMA_I8_ACC(acc[nb], a, bq[nb * KSTEPS + s]);
+        if (s == 0) NVDB_MFMA_I8_ZERO(acc[mb][nb], a, bq[nb * KSTEPS]);
+        else NVDB_MFMA_I8_ACC(acc[mb][nb], a, bq[nb * KSTEPS + s]);
       }
-      if (s % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_row0, next_buf, s / PIECE_EVERY);
-      if (s == 1) issue_scales(next_row0, next_buf);
+      if (u % (NREAD / PPW) == NREAD / PPW - 1) issue_piece(next_row0, next_buf, u / (NREAD / PPW));
+      if (u == 1) issue_scales(next_row0, next_buf);
     }
-    if constexpr (NB == 2) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
-    else asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]));
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(acc[mb][nb]));
 
     // ---- stage 1: can any of my NB x 16 hi-plane values H_r * scale_r reach its first-stage threshold? ----------
     // (exact per value: cvt + mul, then a max tree per block and one compare; a cheaper bound such as
     //  max(H) * max(scale) lets a quarter of the tiles through, and a tile costs what its slowest wave costs)
-    float d1[NB];
+    float d1[MB][NB];
+    float dall = -__builtin_huge_valf();
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      float fh[16];
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) fh[r] = static_cast<float>(acc[nb][r]) * scv[r];
-      float m = vmax3(fh[0], fh[1], fh[2]);
+      for (int nb = 0; nb < NB; ++nb) {
+        float fh[16];
 #pragma unroll
-      for (int r = 3; r < 15; r += 2) m = vmax3(m, fh[r], fh[r + 1]);
-      d1[nb] = vmax3(m, fh[15], fh[15]) - t1q[nb];                     // >= 0 iff some value reaches the threshold
-    }
-    if (!__builtin_amdgcn_ballot_w64(vmax3(d1[0], d1[NB - 1], d1[NB - 1]) >= 0.f)) continue;
-    ++n_stage1;
-    const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
+        for (int r = 0; r < 16; ++r) fh[r] = static_cast<float>(acc[mb][nb][r]) * scv[mb][r];
+        float m = vmax3(fh[0], fh[1], fh[2]);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      if (!__builtin_amdgcn_ballot_w64(d1[nb] >= 0.f)) continue;
-      ++n_stage2;
-      // ---- stage 2: the lo plane of this query block, fragments from global memory ---------------------------
-      const signed char* ql = qlo + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 16 * hsel;
-      intx16 lo;
-      float4_t bl[KSTEPS];
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) bl[s] = *reinterpret_cast<const float4_t*>(ql + 32 * s);   // all in flight at once
-#pragma unroll
-      for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(s);
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1);
-        const float4_t a = ar[s % RING];
-        if (s == 0) NVDB_MFMA_I8_ZERO_V(lo, a, bl[s]); else NVDB_MFMA_I8_ACC_V(lo, a, bl[s]);
+        for (int r = 3; r < 15; r += 2) m = vmax3(m, fh[r], fh[r + 1]);
+        d1[mb][nb] = vmax3(m, fh[15], fh[15]) - t1q[nb];                 // >= 0 iff some value reaches the threshold
+        dall = vmax3(dall, d1[mb][nb], d1[mb][nb]);
       }
-      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(lo));
+    if (!__builtin_amdgcn_ballot_w64(dall >= 0.f)) continue;
+    ++n_stage1;
+    const uint32_t row0 = row_lo + (t_lo + t) * TROWS;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float fv = static_cast<float>(acc[nb][r] * 128 + lo[r]) * scv[r];
-        const bool hit = fv >= thr_s[nb];
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-        if (m) {
-          const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
-          if (hit && idx < FILTER_LOGCAP) mylog[idx] = Hit{fv * inv_s[nb], row0 + (r & 3) + 8 * (r >> 2) + 4 * hsel, qid[nb], 0u};
-          wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if (!__builtin_amdgcn_ballot_w64(d1[mb][nb] >= 0.f)) continue;
+        ++n_stage2;
+        // ---- stage 2: the lo plane of this (row block, query block), fragments from global memory in two halves ----
+        const signed char* ql = qlo + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 16 * hsel;
+        intx16 lo;
+        constexpr int HALF = KSTEPS / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float4_t bl[HALF];
+#pragma unroll
+          for (int s = 0; s < HALF; ++s) bl[s] = *reinterpret_cast<const float4_t*>(ql + 32 * (h * HALF + s));   // all in flight at once
+#pragma unroll
+          for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(MB * (h * HALF + s) + mb);
+#pragma unroll
+          for (int s = 0; s < HALF; ++s) {
+            if (s + RING - 1 < HALF) ar[(s + RING - 1) % RING] = read_a(MB * (h * HALF + s + RING - 1) + mb);
+            const float4_t a = ar[s % RING];
+            if (h == 0 && s == 0) NVDB_MFMA_I8_ZERO_V(lo, a, bl[s]); else NVDB_MFMA_I8_ACC_V(lo, a, bl[s]);
+          }
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(lo));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float fv = static_cast<float>(acc[mb][nb][r] * 128 + lo[r]) * scv[mb][r];
+          const bool hit = fv >= thr_s[nb];
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+          if (m) {
+            const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+            if (hit && idx < FILTER_LOGCAP) mylog[idx] = Hit{fv * inv_s[nb], row0 + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * hsel, qid[nb], 0u};
+            wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
+          }
         }
       }
-    }
   }
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(prog + static_cast<uint64_t>(stream) * 8 + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (stage_counts && lane == 0 && (n_stage1 | n_stage2)) { atomicAdd(stage_counts, n_stage1); atomicAdd(stage_counts + 1, n_stage2); }

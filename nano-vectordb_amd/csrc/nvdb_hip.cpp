@@ -150,6 +150,8 @@ constexpr uint32_t PROG_SLOTS = 16;   // filter launches per search whose rendez
 
 bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128 || dim == 1024 || dim == 1536; }
 constexpr uint32_t F16_FILTER_MAX_DIM = 1536;
+constexpr uint32_t I8W_TILE_ROWS = 64;                // rows per tile of the int8 two-stage kernel (two 32-row blocks)
+constexpr uint32_t PAD_ROWS = 64;                     // zero rows every library-owned corpus / shadow is padded with: the largest tile
 bool i8_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 256; }   // int8 rows: stride % 256 == 0
 
 nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
@@ -175,7 +177,7 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
     uint32_t sdim = 128;
     while (!f16_filter_dim(sdim) || sdim < c->dim) sdim += 128;
     const size_t count = static_cast<size_t>(c->n) * sdim;
-    const size_t pad = static_cast<size_t>(FILTER_ROWS) * sdim * 2 + 4096;
+    const size_t pad = static_cast<size_t>(PAD_ROWS) * sdim * 2 + 4096;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow16), count * 2 + pad));
     HIPCHK(c, hipMemsetAsync(reinterpret_cast<char*>(c->shadow16) + count * 2, 0, pad, c->stream));
     HIPCHK(c, hipMemsetAsync(bits, 0, 4, c->stream));
@@ -191,8 +193,8 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   if (c->dtype == NVDB_DTYPE_I8 && c->dim <= 768 && !i8_filter_dim(c->dim) && c->opt_f32_shadow) {
     uint32_t sdim = 256;
     while (sdim < c->dim) sdim += 256;
-    const size_t count = static_cast<size_t>(c->n) * sdim, pad = static_cast<size_t>(FILTER_ROWS) * sdim + 4096;
-    const size_t n_pad = (static_cast<size_t>(c->n) + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS + FILTER_ROWS;
+    const size_t count = static_cast<size_t>(c->n) * sdim, pad = static_cast<size_t>(PAD_ROWS) * sdim + 4096;
+    const size_t n_pad = (static_cast<size_t>(c->n) + PAD_ROWS - 1) / PAD_ROWS * PAD_ROWS + PAD_ROWS;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow8), count + pad));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow8_scales), n_pad * 4));
     HIPCHK(c, hipMemsetAsync(c->shadow8 + count, 0, pad, c->stream));
@@ -476,10 +478,11 @@ nvdb_status launch_boot_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_
 template <int DIM, int NB>
 nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
                                   uint32_t nq_pad, uint32_t cap) {
-  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * DIM + 4 * 1024);
+  constexpr size_t lds = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + 4 * 1024);       // 64-row tiles, three stages
   uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
   if (nwg == 0) nwg = QT;
   nvdb_status st;
+  if ((row_hi - row_lo) % I8W_TILE_ROWS) return fail(c, NVDB_ERR_INTERNAL, "int8 two-stage kernel: row range is not a multiple of its 64-row tile");
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
   const signed char* qhi = static_cast<const signed char*>(c->q16.p);
   const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * DIM;
@@ -487,12 +490,12 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
 #define NVDB_I8W_LAUNCH(SYNCV, PROG, MASK, LEAD)                                                                                  \
   {                                                                                                                             \
-    const void* fn = reinterpret_cast<const void*>(filter_i8w_kernel<DIM, NB, 6, SYNCV>);                                           \
+    const void* fn = reinterpret_cast<const void*>(filter_i8w_kernel<DIM, NB, 6, SYNCV, 2>);                                           \
     if (!c->lds_attr_set.count(fn)) {                                                                                           \
       HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
       c->lds_attr_set.insert(fn);                                                                                               \
     }                                                                                                                           \
-    hipExtLaunchKernelGGL((filter_i8w_kernel<DIM, NB, 6, SYNCV>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
+    hipExtLaunchKernelGGL((filter_i8w_kernel<DIM, NB, 6, SYNCV, 2>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), PROG, MASK, LEAD, counts); \
   }
@@ -646,7 +649,8 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // Whole tiles: a corpus this library allocated is zero-padded to a multiple of 32 rows (the padded rows are
   // dropped when the wave files its survivors); for an adopted corpus the ragged tail goes to the exact kernel.
   const bool padded = c->owned || c->shadow16 != nullptr || c->shadow8 != nullptr;          // a shadow copy is always ours, hence padded
-  const uint32_t n_al = padded ? (n + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS : n / FILTER_ROWS * FILTER_ROWS;
+  const uint32_t tile_rows = i8_two_stage(c) ? I8W_TILE_ROWS : FILTER_ROWS;    // chunk boundaries are whole tiles of the streaming kernel
+  const uint32_t n_al = padded ? (n + tile_rows - 1) / tile_rows * tile_rows : n / tile_rows * tile_rows;
   uint32_t r = 0;
   uint64_t size;
   // chunk i covers (growth-1) x the rows seen before it.  fp16: 8 (flat between 4 and 8).  int8 batches > 128: 3 --
@@ -667,8 +671,8 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     size = static_cast<uint64_t>(boot_rows) * growth;
   } else {
     // bootstrap chunk [0,r) on the exact kernel; r is a multiple of the 32-row MFMA tile
-    r = std::min<uint32_t>(n_al, (static_cast<uint32_t>(c->opt_chunk0) + FILTER_ROWS - 1) / FILTER_ROWS * FILTER_ROWS);
-    if (r > n) r = n / FILTER_ROWS * FILTER_ROWS;
+    r = std::min<uint32_t>(n_al, (static_cast<uint32_t>(c->opt_chunk0) + tile_rows - 1) / tile_rows * tile_rows);
+    if (r > n) r = n / tile_rows * tile_rows;
     if ((st = launch_scan_exact(c, s, 0, r, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
     if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
     size = static_cast<uint64_t>(r) * (growth - 1);
@@ -775,7 +779,7 @@ nvdb_status nvdb_hip_upload_corpus(nvdb_hip_ctx* c, const void* rows, const floa
   HIPCHK(c, hipSetDevice(c->device));
   free_corpus(c);
   const size_t bytes = static_cast<size_t>(n) * dim * bpe_of(dtype);
-  const size_t pad = static_cast<size_t>(FILTER_ROWS) * dim * bpe_of(dtype) + 4096;   // zero rows up to a whole 32-row tile (+ slack for vector loads)
+  const size_t pad = static_cast<size_t>(PAD_ROWS) * dim * bpe_of(dtype) + 4096;   // zero rows up to a whole tile (+ slack for vector loads)
   HIPCHK(c, hipMalloc(&c->rows, bytes + pad));
   HIPCHK(c, hipMemset(static_cast<char*>(c->rows) + bytes, 0, pad));
   c->owned = true;
@@ -785,8 +789,8 @@ nvdb_status nvdb_hip_upload_corpus(nvdb_hip_ctx* c, const void* rows, const floa
     HIPCHK(c, hipMemcpy(static_cast<char*>(c->rows) + off, static_cast<const char*>(rows) + off, take, hipMemcpyHostToDevice));
   }
   if (dtype == NVDB_DTYPE_I8) {
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), (n + FILTER_ROWS) * sizeof(float)));
-    HIPCHK(c, hipMemset(c->scales + n, 0, FILTER_ROWS * sizeof(float)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), (n + PAD_ROWS) * sizeof(float)));
+    HIPCHK(c, hipMemset(c->scales + n, 0, PAD_ROWS * sizeof(float)));
     HIPCHK(c, hipMemcpy(c->scales, scales, n * sizeof(float), hipMemcpyHostToDevice));
   }
   c->n = n; c->dim = dim; c->dtype = dtype; c->row_base = global_row_base;
@@ -813,13 +817,13 @@ nvdb_status nvdb_hip_generate_corpus(nvdb_hip_ctx* c, uint64_t seed, uint64_t n,
   HIPCHK(c, hipSetDevice(c->device));
   free_corpus(c);
   const size_t bytes = static_cast<size_t>(n) * dim * bpe_of(dtype);
-  const size_t pad = static_cast<size_t>(FILTER_ROWS) * dim * bpe_of(dtype) + 4096;
+  const size_t pad = static_cast<size_t>(PAD_ROWS) * dim * bpe_of(dtype) + 4096;
   HIPCHK(c, hipMalloc(&c->rows, bytes + pad));
   HIPCHK(c, hipMemset(static_cast<char*>(c->rows) + bytes, 0, pad));
   c->owned = true;
   if (dtype == NVDB_DTYPE_I8) {
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), (n + FILTER_ROWS) * sizeof(float)));
-    HIPCHK(c, hipMemset(c->scales + n, 0, FILTER_ROWS * sizeof(float)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), (n + PAD_ROWS) * sizeof(float)));
+    HIPCHK(c, hipMemset(c->scales + n, 0, PAD_ROWS * sizeof(float)));
   }
   c->n = n; c->dim = dim; c->dtype = dtype; c->row_base = global_row_base;
   // launch in slabs so that a single launch stays well inside the grid-size limit
