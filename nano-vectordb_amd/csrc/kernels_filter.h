@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   constexpr int NFRAG = NQB * KS, NFRAG_A = NFRAG < 64 ? NFRAG : 64, NFRAG_V = NFRAG - NFRAG_A;
   constexpr int NREAD = MB * KS;                   // A fragments per tile (MB row blocks x KS)
   static_assert(DIM % 128 == 0 && PIECES % 4 == 0 && NREAD % PPW == 0, "shape");
-  static_assert((MB == 1 || MB == 2) && (NQB == 2 || NQB == 4) && NQB * KS * 4 <= 384 && STAGE_BYTES * FILTER_STAGES <= 160 * 1024, "registers / LDS");
+  static_assert((MB == 1 || MB == 2 || MB == 4) && (NQB == 2 || NQB == 4) && NQB * KS * 4 <= 384 && STAGE_BYTES * FILTER_STAGES <= 160 * 1024, "registers / LDS");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -610,14 +610,15 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     float dmax[NQB];
 #pragma unroll
     for (int nb = 0; nb < NQB; ++nb) {
-      float m = vmax3(acc[0][nb][0], acc[0][nb][1], acc[0][nb][2]);
-      if constexpr (MB == 2) {
-        m = vmax3(m, acc[0][nb][3], acc[MB - 1][nb][0]);
-        m = vmax3(m, acc[MB - 1][nb][1], acc[MB - 1][nb][2]);
-        m = vmax3(m, acc[MB - 1][nb][3], acc[MB - 1][nb][3]);
-      } else {
-        m = vmax3(m, acc[0][nb][3], acc[0][nb][3]);
-      }
+      float v[4 * MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * mb + r] = acc[mb][nb][r];
+      float m = vmax3(v[0], v[1], v[2]);
+#pragma unroll
+      for (int x = 3; x + 1 < 4 * MB; x += 2) m = vmax3(m, v[x], v[x + 1]);
+      m = vmax3(m, v[4 * MB - 1], v[4 * MB - 1]);                  // 4*MB is even: one value is left over
       dmax[nb] = m - thr_s[nb];                      // >= 0 iff m >= thr (a difference of floats never rounds across 0)
     }
     const bool any = (NQB == 4 ? vmax3(vmax3(dmax[0], dmax[1], dmax[NQB / 2]), dmax[NQB - 1], dmax[NQB - 1])

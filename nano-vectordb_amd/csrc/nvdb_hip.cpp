@@ -342,9 +342,10 @@ bool filter_supported(const nvdb_hip_ctx* c) {
 template <int DIM, int NB>
 nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
                               uint32_t cap) {
-  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * DIM * 2;
+  constexpr int MBK = DIM <= 384 ? 4 : 2;                 // 16-row blocks per tile of the m16 build: 64-row tiles up to d=384
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * DIM * 2 * (DIM <= 384 ? 2 : 1);
   const bool m16 = (NB == 2) && c->opt_mfma16;
-  const void* fn = m16 ? reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM>) : reinterpret_cast<const void*>(filter_f16_kernel<DIM, NB>);
+  const void* fn = m16 ? reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM, 6, false, false, 0, MBK>) : reinterpret_cast<const void*>(filter_f16_kernel<DIM, NB>);
   if (!c->lds_attr_set.count(fn)) {
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     c->lds_attr_set.insert(fn);
@@ -359,19 +360,19 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
     if (sync) {
       uint32_t* prog = nullptr;                    // unused / not-yet-started slots read 0xFFFFFFFF = "far ahead"
       if ((st = next_prog_region(c, s, nwg, &prog))) return st;
-      const void* fs = reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM, 6, true>);
+      const void* fs = reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM, 6, true, false, 0, MBK>);
       if (!c->lds_attr_set.count(fs)) {
         HIPCHK(c, hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         c->lds_attr_set.insert(fs);
       }
-      hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM, 6, true>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
+      hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM, 6, true, false, 0, MBK>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
                                                                 static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                                 static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
                                                                 static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap),
                                                                 prog, static_cast<uint32_t>(c->opt_sync_every - 1),
                                                                 static_cast<uint32_t>(c->opt_sync_lead));
     } else {
-      hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
+      hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM, 6, false, false, 0, MBK>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
                                                        static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                        static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
                                                        static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), nullptr, 0u, 0u);
@@ -649,7 +650,10 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // Whole tiles: a corpus this library allocated is zero-padded to a multiple of 32 rows (the padded rows are
   // dropped when the wave files its survivors); for an adopted corpus the ragged tail goes to the exact kernel.
   const bool padded = c->owned || c->shadow16 != nullptr || c->shadow8 != nullptr;          // a shadow copy is always ours, hence padded
-  const uint32_t tile_rows = i8_two_stage(c) ? I8W_TILE_ROWS : FILTER_ROWS;    // chunk boundaries are whole tiles of the streaming kernel
+  // chunk boundaries are whole tiles of the streaming kernel: 64 rows for the int8 two-stage kernel and for the m16
+  // fp16 build at d <= 384, 32 otherwise
+  const bool f16_wide_tiles = c->dtype != NVDB_DTYPE_I8 && c->fdim <= 384 && filter_nb(c, nq) == 2 && c->opt_mfma16;
+  const uint32_t tile_rows = (i8_two_stage(c) || f16_wide_tiles) ? I8W_TILE_ROWS : FILTER_ROWS;
   const uint32_t n_al = padded ? (n + tile_rows - 1) / tile_rows * tile_rows : n / tile_rows * tile_rows;
   uint32_t r = 0;
   uint64_t size;
