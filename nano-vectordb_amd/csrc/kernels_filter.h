@@ -133,7 +133,7 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
 
 // One survivor of the filter, logged by the wave that found it (16 bytes, one dwordx4 store).
 struct Hit { float score; uint32_t row; uint32_t qid; uint32_t pad; };
-constexpr uint32_t FILTER_LOGCAP = 512;            // entries per wave and launch
+constexpr uint32_t FILTER_LOGCAP = 4096;           // entries per wave and launch (64 KB of log per wave; typical use: < 100)
 
 // where the logged survivors go when the wave has finished its stream
 struct ScatterArgs {

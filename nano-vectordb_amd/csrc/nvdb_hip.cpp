@@ -64,6 +64,7 @@ struct nvdb_hip_ctx {
   int64_t opt_i8_wide = 1;
   void* pinned = nullptr;                           // pinned host staging of small calls: status words, results, queries
   size_t pinned_bytes = 0;
+  uint32_t cap_hint = 0;                            // this corpus has needed the longest candidate lists before: start with them
   bool stats_lazy = false;                          // stats.candidates not read back yet (nvdb_hip_get_stats does it)
   hipEvent_t launch_e0 = nullptr, launch_e1 = nullptr;   // attached to the next filter launch (hipExtLaunchKernelGGL): its own start/stop timestamps, no extra packets
   std::vector<hipEvent_t> kl_pool;                  // recycled events of collected launches
@@ -142,6 +143,7 @@ void free_corpus(nvdb_hip_ctx* c) {
   if (c->shadow8) { (void)hipFree(c->shadow8); c->shadow8 = nullptr; }
   if (c->shadow8_scales) { (void)hipFree(c->shadow8_scales); c->shadow8_scales = nullptr; }
   c->rows = nullptr; c->scales = nullptr; c->owned = false; c->n = 0; c->dim = 0; c->fdim = 0; c->dtype = 0; c->max_norm = 0.f;
+  c->cap_hint = 0;
 }
 
 // dims the fp16 MFMA kernels are instantiated for: multiples of 128 up to 768 (64 queries per wave: their fragments fill
@@ -585,14 +587,14 @@ hipEvent_t get_event(nvdb_hip_ctx* c, size_t idx) {
 
 // Enqueue one whole search of nq (<= 2048) queries resident at dev_q.  No host synchronisation.
 nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint32_t nq, uint32_t k, uint64_t* dev_out_ids,
-                        float* dev_out_scores, int force_path, bool time_filter) {
+                        float* dev_out_scores, int force_path, bool time_filter, uint32_t cap_override = 0) {
   const uint32_t k_eff = static_cast<uint32_t>(std::min<uint64_t>(k, c->n));
   const uint32_t n = static_cast<uint32_t>(c->n);
   int path = force_path ? force_path : static_cast<int>(c->opt_path);
   if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
   if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 1536 or an int8 corpus with dim <= 768");
 
-  uint32_t cap = c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : (nq <= 64 ? SELECT_MAX_CAP : 2048u);
+  uint32_t cap = cap_override ? cap_override : c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : std::max<uint32_t>(c->cap_hint, nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
   if (cap < 4 * k_eff) cap = std::min<uint32_t>(SELECT_MAX_CAP, 4 * k_eff);
   const uint32_t QPB = 128u * filter_nb(c, nq);              // queries per filter workgroup
@@ -991,11 +993,23 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     if ((st = fetch())) return st;
     nvdb_hip_scan_stats part = c->stats;
     if (pin_status[0] | pin_status[1] | pin_status[6]) {
-      // self-check tripped (rare): exact counts, then redo the batch on the always-correct exact path
+      // self-check tripped (rare): exact counts for the statistics, then redo the batch -- first on the filter path with
+      // the longest candidate lists the select kernel can sort (near-duplicate-heavy corpora: thousands of rows inside
+      // the filter's error band of the k-th score; re-scoring them is cheap, only the list was too short), and if that
+      // is still not enough, or the bound itself was violated, on the always-correct exact path
       nvdb_status chk = nvdb_hip_search_check(c, &part);
       if (chk == NVDB_ERR_HIP) return chk;
-      if ((st = search_core(c, s, dq, nq, k, oi, os, 1, false))) return st;
-      if ((st = fetch())) return st;
+      bool done = false;
+      if (part.path == 2 && !pin_status[0] && c->last_cap < SELECT_MAX_CAP) {
+        if ((st = search_core(c, s, dq, nq, k, oi, os, 2, false, SELECT_MAX_CAP))) return st;
+        if ((st = fetch())) return st;
+        done = !(pin_status[0] | pin_status[1] | pin_status[6]);
+        if (done) c->cap_hint = SELECT_MAX_CAP;
+      }
+      if (!done) {
+        if ((st = search_core(c, s, dq, nq, k, oi, os, 1, false))) return st;
+        if ((st = fetch())) return st;
+      }
       c->stats = part;
     } else {
       part.i8_stage1_tiles = pin_status[4]; part.i8_stage2_blocks = pin_status[5];
@@ -1035,9 +1049,21 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     nvdb_status chk = nvdb_hip_search_check(c, &part);
     if (chk == NVDB_ERR_HIP) return chk;
     if (chk == NVDB_ERR_INTERNAL) {
-      // self-check tripped: redo this sub-batch on the always-correct exact path (still on the GPU)
-      if ((st = search_core(c, s, dq, b, k, oi, os, 1, false))) return st;
-      HIPCHK(c, hipStreamSynchronize(s));
+      // self-check tripped: longest lists first, then the always-correct exact path (see the small-call path above)
+      bool done = false;
+      if (part.path == 2 && !part.bound_violations && c->last_cap < SELECT_MAX_CAP) {
+        if ((st = search_core(c, s, dq, b, k, oi, os, 2, false, SELECT_MAX_CAP))) return st;
+        HIPCHK(c, hipStreamSynchronize(s));
+        nvdb_hip_scan_stats again{};
+        const nvdb_status chk2 = nvdb_hip_search_check(c, &again);
+        if (chk2 == NVDB_ERR_HIP) return chk2;
+        done = (chk2 == NVDB_OK);
+        if (done) c->cap_hint = SELECT_MAX_CAP;
+      }
+      if (!done) {
+        if ((st = search_core(c, s, dq, b, k, oi, os, 1, false))) return st;
+        HIPCHK(c, hipStreamSynchronize(s));
+      }
     }
     total.path = std::max(total.path, part.path);
     total.chunks += part.chunks; total.rows_scanned += part.rows_scanned; total.candidates += part.candidates;

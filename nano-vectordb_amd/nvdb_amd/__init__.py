@@ -202,6 +202,8 @@ class HipContext:
 
     # -- corpus
     def upload_corpus(self, rows, dtype, scales=None, row_base=0):
+        if dtype == DT_F16 and getattr(rows, "dtype", None) == np.float16:
+            rows = rows.view(np.uint16)                     # IEEE half bits, not a value conversion to integers
         rows = np.ascontiguousarray(rows, dtype=_NP_OF[dtype])
         sc = np.ascontiguousarray(scales, dtype=np.float32) if scales is not None else None
         self._chk(self.lib.nvdb_hip_upload_corpus(self.h, rows.ctypes.data, sc.ctypes.data if sc is not None else None,

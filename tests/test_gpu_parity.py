@@ -384,6 +384,27 @@ def test_non_finite_queries_take_the_exact_path(ctx, oracle, tag):
     _check_against_oracle(oracle, base, po.DT_F16 if tag == "f16" else po.DT_I8, scales, queries[good], fi[good], fs[good], k, "nonfinite/rest")
 
 
+def test_near_duplicate_clusters_overflow_the_short_lists_but_stay_exact(ctx, oracle):
+    """Tight clusters: thousands of rows lie inside the filter's error band of the k-th score, more than the default
+    2048-entry lists hold.  The search is redone with the longest lists (and, failing that, on the exact path); either
+    way ids and score bits equal the CPU path."""
+    n, d, nq, k, C = 150000, 768, 200, 10, 40               # ~3750 rows per cluster
+    rs = np.random.RandomState(11)
+    cent = rs.randn(C, d).astype(np.float32); cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    x = cent[rs.randint(0, C, size=n)] + np.float32(0.05) * rs.randn(n, d).astype(np.float32) / np.float32(np.sqrt(d))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    base = oracle.f32_to_f16(x.astype(np.float32))
+    q = cent[rs.randint(0, C, size=nq)] + np.float32(0.05) * rs.randn(nq, d).astype(np.float32) / np.float32(np.sqrt(d))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    ctx.upload_corpus(base, po.DT_F16)
+    ctx.set_option("path", 2)
+    ids, sc = ctx.search_batch(q, k)
+    st = ctx.stats()
+    ctx.set_option("path", 0)
+    assert st["overflow_queries"] > 0 and st["bound_violations"] == 0, st       # the first attempt did overflow
+    _check_against_oracle(oracle, base, po.DT_F16, None, q[:48], ids[:48], sc[:48], k, "near-dup clusters")
+
+
 def test_overflow_falls_back_to_exact_path(ctx, oracle):
     """Adversarial order (rows sorted by score ascending for the query) overflows the candidate
     lists; the library must notice and still return the exact answer."""
