@@ -352,7 +352,9 @@ __global__ __launch_bounds__(256) void select_kernel(
       return;
     }
     const float sl = slack ? slack[q] : 0.f;
-    const float t = s_kth - sl;                   // s_kth stays -inf when m < k
+    // thresholds only ever rise: the previous one stays a valid lower bound of (k-th best - slack) when this list is
+    // shorter than k (s_kth = -inf) or its k-th entry is lower (bootstrap rows that are not part of the first chunk)
+    const float t = fmaxf(s_kth - sl, thr[q]);
     uint32_t local = 0;
 #pragma unroll
     for (int u = 0; u < 2; ++u) if (rk[u] != 0xFFFFFFFFu) local += (sl > 0.f ? (my[u].score >= t) : (rk[u] < k)) ? 1u : 0u;
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void select_kernel(
   }
   const float kth = (m >= k) ? e[k - 1].score : NEG_INF;
   const float sl = slack ? slack[q] : 0.f;
-  const float t = kth - sl;
+  const float t = fmaxf(kth - sl, thr[q]);        // thresholds only ever rise (see the short-list path above)
   if (tid == 0) s_keep = 0;
   __syncthreads();
   uint32_t local = 0;

@@ -143,7 +143,20 @@ struct ScatterArgs {
   uint32_t* log_overflow;    // one word: some wave's log overflowed (unknown queries lost entries)
   uint32_t cap;
   uint32_t n_rows;           // rows >= n_rows are the zero rows that pad the corpus to whole tiles
+  // Tile order.  The chunk scheme assumes that a chunk is a fair sample of the corpus (then k * chunk / rows_seen rows
+  // clear the previous threshold, whatever the data); a corpus stored in topic / cluster order breaks that and floods
+  // the lists.  So logical tile g (what row_lo, row_hi and the streams count in) is physical tile perm_tile(g): an odd
+  // multiplier modulo the next power of two, cycle-walked back into [0, perm_T) -- a bijection of the corpus' tiles
+  // that costs a handful of scalar instructions per tile.  perm_mask == 0: identity.
+  uint32_t perm_mul, perm_mask, perm_T;
 };
+
+__device__ __forceinline__ uint32_t perm_tile(uint32_t g, const ScatterArgs& a) {
+  if (a.perm_mask == 0) return g;
+  uint32_t x = g;
+  do { x = (x * a.perm_mul + 0x9E3779B1u) & a.perm_mask; } while (x >= a.perm_T);
+  return x;
+}
 
 // File this wave's logged survivors under their queries (cand[qid][slot], slot from an atomic counter).  Runs
 // once, after the tile loop: nothing is in flight any more, so the returning atomics cost nothing in the loop.
@@ -271,10 +284,11 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
   const char* gbase = reinterpret_cast<const char*>(rows);
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
   // tile t_rel of this stream (clamped: past-the-end tiles re-load the last one, harmlessly)
+  const uint32_t g_lo = row_lo / FILTER_ROWS + t_lo;          // logical index of my first tile in the whole corpus
+  auto tile_phys = [&](uint32_t t_rel) -> uint32_t { return perm_tile(g_lo + (t_rel < NT ? t_rel : NT - 1), sa); };
   auto tile_ptr = [&](uint32_t t_rel) -> const char* {
-    uint32_t t = t_lo + (t_rel < NT ? t_rel : NT - 1);
-    if constexpr (VAR == 6) t = t_lo + (t_rel & 7u);          // ablation: 8 tiles per stream, L2-resident
-    return gbase + static_cast<uint64_t>(row_lo + t * FILTER_ROWS) * ROW_BYTES;
+    if constexpr (VAR == 6) return gbase + static_cast<uint64_t>(row_lo + (t_lo + (t_rel & 7u)) * FILTER_ROWS) * ROW_BYTES;   // ablation: 8 tiles per stream, L2-resident
+    return gbase + static_cast<uint64_t>(tile_phys(t_rel)) * FILTER_ROWS * ROW_BYTES;
   };
   auto issue_piece = [&](const char* tile, uint32_t buf, int i) {
     glds16(src_off[i], tile, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
@@ -350,14 +364,20 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
       // (a lower bound generator for the first thresholds: the k-th largest of T tile maxima is <= the
       //  k-th largest score overall; the host discards these entries after the threshold is taken and
       //  the same rows are scanned again by the normal build, so nothing is lost or duplicated)
-      const uint32_t tile = t_lo + t;
-      const uint32_t row0b = row_lo + tile * FILTER_ROWS;
+      const uint32_t tile = t_lo + t;                          // list slot: logical
+      const uint32_t row0b = tile_phys(t) * FILTER_ROWS;       // rows: physical
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        float best = acc[nb][0];
+        // rows past the end of the corpus (zero padding of the last tile, which the permuted order can bring here) are
+        // not rows: they must not stand in for one of the T rows the threshold argument counts
+        float best = -__builtin_huge_valf();
         uint32_t brow = 0;
 #pragma unroll
-        for (int r = 1; r < 16; ++r) { const bool gt = acc[nb][r] > best; best = gt ? acc[nb][r] : best; brow = gt ? static_cast<uint32_t>(r) : brow; }
+        for (int r = 0; r < 16; ++r) {
+          const bool real = row0b + (r & 3) + 8 * (r >> 2) + 4 * hsel < sa.n_rows;
+          const bool gt = real && acc[nb][r] > best;
+          best = gt ? acc[nb][r] : best; brow = gt ? static_cast<uint32_t>(r) : brow;
+        }
         uint32_t grow = row0b + (brow & 3) + 8 * (brow >> 2) + 4 * hsel;
         const float obest = __shfl_xor(best, 32);
         const uint32_t orow = static_cast<uint32_t>(__shfl_xor(static_cast<int>(grow), 32));
@@ -387,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     if (__builtin_amdgcn_ballot_w64(any)) {
       // rare path: log the survivors in this wave's own region (plain 16-byte stores, no atomics,
       // nothing to wait for); scatter_own_log files them under their queries when the stream is done.
-      const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
+      const uint32_t row0 = tile_phys(t) * FILTER_ROWS;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -530,9 +550,10 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
 
   const char* gbase = reinterpret_cast<const char*>(rows);
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
+  const uint32_t g_lo = row_lo / TROWS + t_lo;                // logical index of my first tile in the whole corpus
+  auto tile_phys = [&](uint32_t t_rel) -> uint32_t { return perm_tile(g_lo + (t_rel < NT ? t_rel : NT - 1), sa); };
   auto tile_ptr = [&](uint32_t t_rel) -> const char* {
-    const uint32_t t = t_lo + (t_rel < NT ? t_rel : NT - 1);
-    return gbase + static_cast<uint64_t>(row_lo + t * TROWS) * ROW_BYTES;
+    return gbase + static_cast<uint64_t>(tile_phys(t_rel)) * TROWS * ROW_BYTES;
   };
   auto issue_piece = [&](const char* tile, uint32_t buf, int i) {
     glds16(src_off[i], tile, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
@@ -624,7 +645,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     const bool any = (NQB == 4 ? vmax3(vmax3(dmax[0], dmax[1], dmax[NQB / 2]), dmax[NQB - 1], dmax[NQB - 1])
                                : vmax3(dmax[0], dmax[1], dmax[1])) >= 0.f;
     if (__builtin_amdgcn_ballot_w64(any)) {
-      const uint32_t row0 = row_lo + (t_lo + t) * TROWS;
+      const uint32_t row0 = tile_phys(t) * TROWS;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -786,7 +807,8 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
 
   const char* gbase = reinterpret_cast<const char*>(rows);
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
-  auto tile_row0 = [&](uint32_t t_rel) -> uint32_t { return row_lo + (t_lo + (t_rel < NT ? t_rel : NT - 1)) * FILTER_ROWS; };
+  const uint32_t g_lo = row_lo / FILTER_ROWS + t_lo;          // logical index of my first tile in the whole corpus
+  auto tile_row0 = [&](uint32_t t_rel) -> uint32_t { return perm_tile(g_lo + (t_rel < NT ? t_rel : NT - 1), sa) * FILTER_ROWS; };
   auto issue_piece = [&](uint32_t row0, uint32_t buf, int i) {
     glds16(src_off[i], gbase + static_cast<uint64_t>(row0) * ROW_BYTES, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
   };
@@ -862,12 +884,16 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
     for (int r = 3; r < 15; r += 2) fmx = vmax3(fmx, fv[r], fv[r + 1]);
     const bool any = vmax3(fmx, fv[15], fv[15]) >= thr_s;
     if constexpr (BOOT) {
-      const uint32_t tile = t_lo + t;
-      const uint32_t row0b = row_lo + tile * FILTER_ROWS;
-      float best = fv[0];
+      const uint32_t tile = t_lo + t;                          // list slot: logical
+      const uint32_t row0b = tile_row0(t);                     // rows: physical
+      float best = -__builtin_huge_valf();                     // padding rows are not rows (see filter_f16_kernel)
       uint32_t brow = 0;
 #pragma unroll
-      for (int r = 1; r < 16; ++r) { const bool gt = fv[r] > best; best = gt ? fv[r] : best; brow = gt ? static_cast<uint32_t>(r) : brow; }
+      for (int r = 0; r < 16; ++r) {
+        const bool real = row0b + (r & 3) + 8 * (r >> 2) + 4 * hsel < sa.n_rows;
+        const bool gt = real && fv[r] > best;
+        best = gt ? fv[r] : best; brow = gt ? static_cast<uint32_t>(r) : brow;
+      }
       uint32_t grow = row0b + (brow & 3) + 8 * (brow >> 2) + 4 * hsel;
       const float obest = __shfl_xor(best, 32);
       const uint32_t orow = static_cast<uint32_t>(__shfl_xor(static_cast<int>(grow), 32));
@@ -876,7 +902,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
       continue;
     }
     if (__builtin_amdgcn_ballot_w64(any)) {
-      const uint32_t row0 = row_lo + (t_lo + t) * FILTER_ROWS;
+      const uint32_t row0 = tile_row0(t);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const bool hit = fv[r] >= thr_s;
@@ -992,7 +1018,8 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
 
   const char* gbase = reinterpret_cast<const char*>(rows);
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
-  auto tile_row0 = [&](uint32_t t_rel) -> uint32_t { return row_lo + (t_lo + (t_rel < NT ? t_rel : NT - 1)) * TROWS; };
+  const uint32_t g_lo = row_lo / TROWS + t_lo;                // logical index of my first tile in the whole corpus
+  auto tile_row0 = [&](uint32_t t_rel) -> uint32_t { return perm_tile(g_lo + (t_rel < NT ? t_rel : NT - 1), sa) * TROWS; };
   auto issue_piece = [&](uint32_t row0, uint32_t buf, int i) {
     glds16(src_off[i], gbase + static_cast<uint64_t>(row0) * ROW_BYTES, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
   };
@@ -1084,7 +1111,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
       }
     if (!__builtin_amdgcn_ballot_w64(dall >= 0.f)) continue;
     ++n_stage1;
-    const uint32_t row0 = row_lo + (t_lo + t) * TROWS;
+    const uint32_t row0 = tile_row0(t);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll

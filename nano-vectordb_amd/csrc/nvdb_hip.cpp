@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <string>
@@ -64,6 +65,8 @@ struct nvdb_hip_ctx {
   int64_t opt_i8_wide = 1;
   void* pinned = nullptr;                           // pinned host staging of small calls: status words, results, queries
   size_t pinned_bytes = 0;
+  bool perm_on = false;                             // this search streams tiles in permuted order (set by search_core)
+  int64_t opt_tile_permute = 1;
   uint32_t cap_hint = 0;                            // this corpus has needed the longest candidate lists before: start with them
   bool stats_lazy = false;                          // stats.candidates not read back yet (nvdb_hip_get_stats does it)
   hipEvent_t launch_e0 = nullptr, launch_e1 = nullptr;   // attached to the next filter launch (hipExtLaunchKernelGGL): its own start/stop timestamps, no extra packets
@@ -322,9 +325,24 @@ nvdb_status next_prog_region(nvdb_hip_ctx* c, hipStream_t s, uint32_t nwg, uint3
   return NVDB_OK;
 }
 
-ScatterArgs scatter_args(nvdb_hip_ctx* c, uint32_t cap) {
-  return ScatterArgs{static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), static_cast<uint32_t*>(c->overflow.p),
-                     static_cast<uint32_t*>(c->misc.p) + 1, cap, static_cast<uint32_t>(c->n)};
+// trows = rows per tile of the kernel being launched (0: identity tile order).  With the permutation on, logical tile g
+// of the corpus' T = ceil-or-floor(n / trows) tiles is streamed from physical tile perm_tile(g) (kernels_filter.h).
+ScatterArgs scatter_args(nvdb_hip_ctx* c, uint32_t cap, uint32_t trows = 0) {
+  ScatterArgs a{static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), static_cast<uint32_t*>(c->overflow.p),
+                static_cast<uint32_t*>(c->misc.p) + 1, cap, static_cast<uint32_t>(c->n), 1u, 0u, 0u};
+  if (trows && c->perm_on) {
+    const bool padded = c->owned || c->shadow16 != nullptr || c->shadow8 != nullptr;
+    const uint32_t n = static_cast<uint32_t>(c->n);
+    const uint32_t T = padded ? (n + trows - 1) / trows : n / trows;
+    if (T >= 64) {
+      uint32_t m = 1;
+      while (m < T) m <<= 1;
+      a.perm_mask = m - 1;
+      a.perm_T = T;
+      a.perm_mul = (static_cast<uint32_t>(0.6180339887 * m) | 1u) & a.perm_mask;    // odd: a bijection modulo the power of two
+    }
+  }
+  return a;
 }
 
 // what the fp16 MFMA kernels stream: the corpus itself, or the fp16 shadow of an fp32 corpus
@@ -370,21 +388,21 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
       hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM, 6, true, false, 0, MBK>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
                                                                 static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                                 static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
-                                                                static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap),
+                                                                static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, 16 * MBK),
                                                                 prog, static_cast<uint32_t>(c->opt_sync_every - 1),
                                                                 static_cast<uint32_t>(c->opt_sync_lead));
     } else {
       hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM, 6, false, false, 0, MBK>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
                                                        static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                        static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
-                                                       static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), nullptr, 0u, 0u);
+                                                       static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, 16 * MBK), nullptr, 0u, 0u);
     }
   }
   else
     hipExtLaunchKernelGGL((filter_f16_kernel<DIM, NB>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
                                                      static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                      static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
-                                                     static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), 0u);
+                                                     static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, FILTER_ROWS), 0u);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -410,7 +428,7 @@ nvdb_status launch_filter_k_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo,
     hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM, 6, SYNCV, false, 0, 1, 2>), dim3(nwg), dim3(256), lds, s, c->launch_e0,  \
                           c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi, static_cast<const _Float16*>(c->q16.p), nq, QT,  \
                           static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),                          \
-                          static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), prog,     \
+                          static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, 16), prog, \
                           static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));               \
   }
   if (sync) NVDB_K_LAUNCH(true) else NVDB_K_LAUNCH(false)
@@ -446,13 +464,13 @@ nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
     hipExtLaunchKernelGGL((filter_i8_kernel<DIM, false, 6, true>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT,
                                                                 static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                                 static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
-                                                                scatter_args(c, cap), 0u, prog,
+                                                                scatter_args(c, cap, FILTER_ROWS), 0u, prog,
                                                                 static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));
   } else {
     hipExtLaunchKernelGGL((filter_i8_kernel<DIM>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT,
                                                 static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                 static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
-                                                scatter_args(c, cap), 0u, nullptr, 0u, 0u);
+                                                scatter_args(c, cap, FILTER_ROWS), 0u, nullptr, 0u, 0u);
   }
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
@@ -473,7 +491,7 @@ nvdb_status launch_boot_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_
   filter_f16_kernel<DIM, NB, 7><<<nwg, 256, lds, s>>>(filter_rows_f16(c), 0, n0, static_cast<const _Float16*>(c->q16.p), nq, QT,
                                                       static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                       static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->cand.p),
-                                                      scatter_args(c, cap), cap);
+                                                      scatter_args(c, cap, FILTER_ROWS), cap);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -500,7 +518,7 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
     }                                                                                                                           \
     hipExtLaunchKernelGGL((filter_i8w_kernel<DIM, NB, 6, SYNCV, 2>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
-        static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap), PROG, MASK, LEAD, counts); \
+        static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
   }
   if (sync) {
     uint32_t* prog = nullptr;
@@ -529,7 +547,7 @@ nvdb_status launch_boot_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint
   filter_i8_kernel<DIM, true><<<nwg, 256, lds, s>>>(filter_rows_i8(c), filter_scales_i8(c), 0, n0, qhi, qlo, nq, QT,
                                                     static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),
                                                     static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->cand.p),
-                                                    scatter_args(c, cap), cap, nullptr, 0u, 0u);
+                                                    scatter_args(c, cap, FILTER_ROWS), cap, nullptr, 0u, 0u);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -669,6 +687,8 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const bool mfma_boot = c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
                          boot_rows / FILTER_ROWS <= cap &&
                          (c->dtype == NVDB_DTYPE_I8 || c->fdim <= 768);    // no bootstrap build of the 16-row-tile kernel: exact bootstrap chunk
+  // permuted tile order needs the bootstrap whose entries are discarded (the exact bootstrap chunk keeps rows [0, r))
+  c->perm_on = c->opt_tile_permute && mfma_boot;
   if (mfma_boot) {
     // thresholds from the k-th largest of the 64 tile maxima of rows [0,2048); those rows are then scanned
     // again by the normal build, so the bootstrap entries are discarded (select mode 2)
@@ -881,6 +901,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "sibling_sync") { c->opt_sibling_sync = value ? 1 : 0; }
   else if (k == "f32_shadow") { c->opt_f32_shadow = value ? 1 : 0; }
   else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }
+  else if (k == "tile_permute") { c->opt_tile_permute = value ? 1 : 0; }
   else if (k == "rescore8") { c->opt_rescore8 = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
   else if (k == "refine_v2") { c->opt_refine_v2 = value ? 1 : 0; }
@@ -920,6 +941,13 @@ nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   c->stats.i8_stage1_tiles = misc[4]; c->stats.i8_stage2_blocks = misc[5];
   uint32_t nov = 0;
   for (uint32_t v : ovf) nov += v ? 1u : 0u;
+  if (std::getenv("NVDB_DEBUG_OVERFLOW") && (nov || misc[1])) {
+    std::vector<uint32_t> cn(c->last_nq);
+    (void)hipMemcpy(cn.data(), c->cnt.p, c->last_nq * 4, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "[nvdb debug] log_overflow=%u list flags:", misc[1]);
+    for (uint32_t q = 0; q < c->last_nq; ++q) if (ovf[q]) std::fprintf(stderr, " q%u(cnt=%u)", q, cn[q]);
+    std::fprintf(stderr, "\n");
+  }
   if (misc[1]) nov = c->last_nq;                 // a wave's survivor log overflowed: which queries lost entries is unknown
   c->stats.overflow_queries = nov;
   c->stats.bound_violations = misc[0];

@@ -384,6 +384,39 @@ def test_non_finite_queries_take_the_exact_path(ctx, oracle, tag):
     _check_against_oracle(oracle, base, po.DT_F16 if tag == "f16" else po.DT_I8, scales, queries[good], fi[good], fs[good], k, "nonfinite/rest")
 
 
+@pytest.mark.parametrize("tag,d", [("f16", 768), ("i8", 768), ("f16", 384)])
+def test_corpus_stored_in_cluster_order_does_not_flood_the_lists(ctx, oracle, tag, d):
+    """Rows grouped by cluster (a corpus ingested topic by topic): a query's whole cluster sits in one stretch of rows.
+    In storage order the last chunks would meet thousands of rows above thresholds learnt from unrelated clusters; the
+    filter kernels stream the tiles in a permuted order instead, so every chunk is a fair sample.  No overflow, and
+    ids / score bits equal the CPU path.  (Also the case that showed why thresholds must never fall: the bootstrap
+    rows are not part of the first chunk any more.)"""
+    n, nq, k, C = 160000 + 33, 300, 10, 40
+    rs = np.random.RandomState(12)
+    cent = rs.randn(C, d).astype(np.float32); cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    cid = np.arange(n) * C // n                               # cluster-ordered
+    x = cent[cid] + np.float32(0.5) * rs.randn(n, d).astype(np.float32) / np.float32(np.sqrt(d))
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    if tag == "f16":
+        base, dt, scales = oracle.f32_to_f16(x), po.DT_F16, None
+    else:
+        (base, scales), dt = oracle.quantize_i8(x), po.DT_I8
+    q = cent[rs.randint(0, C, size=nq)] + np.float32(0.5) * rs.randn(nq, d).astype(np.float32) / np.float32(np.sqrt(d))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    ctx.upload_corpus(base, dt, scales)
+    ctx.set_option("path", 2)
+    ids, sc = ctx.search_batch(q, k)
+    st = ctx.stats()
+    ctx.set_option("tile_permute", 0)
+    ctx.search_batch(q, k)
+    st_storage_order = ctx.stats()
+    ctx.set_option("tile_permute", 1)
+    ctx.set_option("path", 0)
+    assert st["path"] == 2 and st["overflow_queries"] == 0 and st["bound_violations"] == 0, st
+    assert st_storage_order["overflow_queries"] > 0, st_storage_order          # what the permutation is for
+    _check_against_oracle(oracle, base, dt, scales, q[:40], ids[:40], sc[:40], k, f"cluster-order/{tag}/d{d}")
+
+
 def test_near_duplicate_clusters_overflow_the_short_lists_but_stay_exact(ctx, oracle):
     """Tight clusters: thousands of rows lie inside the filter's error band of the k-th score, more than the default
     2048-entry lists hold.  The search is redone with the longest lists (and, failing that, on the exact path); either
