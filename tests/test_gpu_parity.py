@@ -438,9 +438,11 @@ def test_near_duplicate_clusters_overflow_the_short_lists_but_stay_exact(ctx, or
     _check_against_oracle(oracle, base, po.DT_F16, None, q[:48], ids[:48], sc[:48], k, "near-dup clusters")
 
 
-def test_overflow_falls_back_to_exact_path(ctx, oracle):
-    """Adversarial order (rows sorted by score ascending for the query) overflows the candidate
-    lists; the library must notice and still return the exact answer."""
+@pytest.mark.parametrize("permute", [0, 1])
+def test_overflow_falls_back_to_exact_path(ctx, oracle, permute):
+    """Candidate lists that overflow (tiny lists here; with the tiles in storage order also the adversarial order: rows
+    sorted by score ascending for query 0): the library must notice, redo the batch with longer lists or on the exact
+    path, and still return the exact answer."""
     n, d, k = 40000, 768, 10
     base32 = nvdb_amd.synth_rows_f32(SEED + 11, 0, n, d)
     q = nvdb_amd.synth_rows_f32(SEED + 12, 0, 16, d)
@@ -449,9 +451,11 @@ def test_overflow_falls_back_to_exact_path(ctx, oracle):
     ctx.upload_corpus(base, po.DT_F16)
     ctx.set_option("path", 2)
     ctx.set_option("cand_cap", 64)
+    ctx.set_option("tile_permute", permute)
     ids, sc = ctx.search_batch(q, k)
     st = ctx.stats()
     ctx.set_option("cand_cap", 0)
+    ctx.set_option("tile_permute", 1)
     ctx.set_option("path", 0)
     assert st["overflow_queries"] >= 1
     _check_against_oracle(oracle, base, po.DT_F16, None, q, ids, sc, k, "overflow")
