@@ -186,6 +186,10 @@ nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* ctx, int variant, uint32
  * ablations 1 = no direct-to-LDS loads, 5 = no LDS reads, 15 = neither.  Same preconditions as the call above. */
 nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* ctx, int variant, uint32_t nq, float seconds, float* out4);
 
+/* Developer aid (host only, no GPU): the physical tile the filter kernels stream for logical tile g of a corpus of n_tiles
+ * tiles -- a bijection of [0, n_tiles) (identity below 64 tiles).  tests/test_cabi_cpu.py checks that property. */
+uint32_t nvdb_permuted_tile(uint32_t g, uint32_t n_tiles);
+
 /* ---------------------------------------------------------------------------------------------
  * exact-L2 refine (rerank of R candidates per query) -- replaces nvdb::cuda_l2_topk_batch
  * (include/nvdb/cuda_refine.h:25-38, src/cuda_refine.cu:839-1173) on the resident corpus

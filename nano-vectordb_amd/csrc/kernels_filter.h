@@ -151,11 +151,22 @@ struct ScatterArgs {
   uint32_t perm_mul, perm_mask, perm_T;
 };
 
-__device__ __forceinline__ uint32_t perm_tile(uint32_t g, const ScatterArgs& a) {
-  if (a.perm_mask == 0) return g;
+__host__ __device__ __forceinline__ uint32_t perm_tile_raw(uint32_t g, uint32_t mul, uint32_t mask, uint32_t T) {
+  if (mask == 0) return g;
   uint32_t x = g;
-  do { x = (x * a.perm_mul + 0x9E3779B1u) & a.perm_mask; } while (x >= a.perm_T);
+  do { x = (x * mul + 0x9E3779B1u) & mask; } while (x >= T);
   return x;
+}
+__device__ __forceinline__ uint32_t perm_tile(uint32_t g, const ScatterArgs& a) { return perm_tile_raw(g, a.perm_mul, a.perm_mask, a.perm_T); }
+
+// the multiplier / mask for T tiles (T < 64: identity)
+__host__ __device__ __forceinline__ void perm_params(uint32_t T, uint32_t& mul, uint32_t& mask) {
+  mul = 1u; mask = 0u;
+  if (T < 64) return;
+  uint32_t m = 1;
+  while (m < T) m <<= 1;
+  mask = m - 1;
+  mul = (static_cast<uint32_t>(0.6180339887 * m) | 1u) & mask;    // odd: a bijection modulo the power of two
 }
 
 // File this wave's logged survivors under their queries (cand[qid][slot], slot from an atomic counter).  Runs

@@ -334,13 +334,8 @@ ScatterArgs scatter_args(nvdb_hip_ctx* c, uint32_t cap, uint32_t trows = 0) {
     const bool padded = c->owned || c->shadow16 != nullptr || c->shadow8 != nullptr;
     const uint32_t n = static_cast<uint32_t>(c->n);
     const uint32_t T = padded ? (n + trows - 1) / trows : n / trows;
-    if (T >= 64) {
-      uint32_t m = 1;
-      while (m < T) m <<= 1;
-      a.perm_mask = m - 1;
-      a.perm_T = T;
-      a.perm_mul = (static_cast<uint32_t>(0.6180339887 * m) | 1u) & a.perm_mask;    // odd: a bijection modulo the power of two
-    }
+    perm_params(T, a.perm_mul, a.perm_mask);
+    a.perm_T = T;
   }
   return a;
 }
@@ -1410,6 +1405,12 @@ nvdb_status nvdb_hip_refine_l2_topk(nvdb_hip_ctx* c, const float* queries, const
 }
 
 // ---- host helpers -----------------------------------------------------------------------------------
+uint32_t nvdb_permuted_tile(uint32_t g, uint32_t n_tiles) {
+  uint32_t mul, mask;
+  perm_params(n_tiles, mul, mask);
+  return perm_tile_raw(g, mul, mask, n_tiles);
+}
+
 void nvdb_synth_rows_f32(uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim, float* out) {
   std::vector<int32_t> raw(dim);
   for (uint64_t r = 0; r < nrows; ++r) {

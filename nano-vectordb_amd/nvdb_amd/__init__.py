@@ -25,7 +25,7 @@ EXPORTS = [
     "nvdb_hip_abi_version", "nvdb_hip_device_count", "nvdb_hip_create", "nvdb_hip_destroy", "nvdb_hip_last_error",
     "nvdb_hip_upload_corpus", "nvdb_hip_adopt_corpus", "nvdb_hip_generate_corpus", "nvdb_hip_corpus_info",
     "nvdb_hip_download_rows", "nvdb_hip_search_batch", "nvdb_hip_search_batch_dev", "nvdb_hip_search_check",
-    "nvdb_hip_get_stats", "nvdb_hip_collect_kernel_times", "nvdb_hip_debug_filter_variant", "nvdb_hip_debug_clock", "nvdb_hip_merge_topk_dev", "nvdb_hip_merge_topk_strided_dev", "nvdb_merge_topk_host", "nvdb_hip_set_option",
+    "nvdb_hip_get_stats", "nvdb_hip_collect_kernel_times", "nvdb_hip_debug_filter_variant", "nvdb_hip_debug_clock", "nvdb_permuted_tile", "nvdb_hip_merge_topk_dev", "nvdb_hip_merge_topk_strided_dev", "nvdb_merge_topk_host", "nvdb_hip_set_option",
     "nvdb_hip_refine_l2_topk", "nvdb_hip_refine_l2_topk_dev", "nvdb_synth_rows_f32", "nvdb_f32_to_f16",
     "nvdb_quantize_i8_rows",
 ]
@@ -104,6 +104,8 @@ def load_library():
                                                 C.POINTER(C.c_double)]
     L.nvdb_hip_debug_filter_variant.argtypes = [vp, C.c_int, u32, u32, f32p]
     L.nvdb_hip_debug_clock.argtypes = [vp, C.c_int, u32, C.c_float, f32p]
+    L.nvdb_permuted_tile.argtypes = [u32, u32]
+    L.nvdb_permuted_tile.restype = u32
     L.nvdb_hip_merge_topk_dev.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp]
     L.nvdb_hip_merge_topk_strided_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, u32, u32, u32, vp, vp, vp]
     L.nvdb_merge_topk_host.argtypes = [vp, vp, u32, u32, u32, vp, vp]

@@ -100,3 +100,14 @@ def test_merge_topk_host_canonical_order(lib):
     sc = np.array([[[0.9, 0.5, 0.5]], [[0.9, 0.5, 0.1]]], dtype=np.float32)
     oi, os_ = nvdb_amd.merge_topk_host(ids, sc)
     assert oi.tolist() == [[2, 5, 7]] and os_.tolist() == [[np.float32(0.9), np.float32(0.9), np.float32(0.5)]]
+
+
+def test_tile_permutation_is_a_bijection():
+    """The filter kernels stream logical tile g from physical tile nvdb_permuted_tile(g, T); every tile must be visited
+    exactly once for any corpus size (odd multiplier modulo the next power of two, cycle-walked into range)."""
+    lib = nvdb_amd.load_library()
+    for T in (1, 2, 63, 64, 65, 100, 1023, 1024, 1025, 1876, 3751, 4097, 65536, 78125, 312500):
+        img = np.fromiter((lib.nvdb_permuted_tile(g, T) for g in range(T)), dtype=np.uint32, count=T)
+        assert img.max() == T - 1 and len(np.unique(img)) == T, T
+        if T >= 1024:                                          # and it spreads: consecutive logical tiles are far apart
+            assert np.median(np.abs(np.diff(img.astype(np.int64)))) > T // 8, T
