@@ -95,6 +95,28 @@ def test_nvdb_bench_rejects_bad_input(files, built):
     assert r.returncode == 3 and "Unknown mode" in r.stderr
 
 
+def test_loader_rejects_what_the_reference_rejects(files, built, tmp_path):
+    """Loader validation (reference src/vector_dataset.cpp:47-70, 98-108): size mismatch under a valid vecbin header,
+    files too small for either header, raw12 with zero dim, raw12 size mismatch.  Same messages; like the reference's
+    tools ours let the exception escape (terminate -> SIGABRT), and both binaries are compared when the real one exists."""
+    good = open(files["b16"], "rb").read()
+    cases = {
+        "truncated.vecbin": (good[:-2], "VecbinHeader ok but file size mismatch"),
+        "padded.vecbin": (good + b"\0" * 8, "VecbinHeader ok but file size mismatch"),
+        "tiny.bin": (b"\1\2\3\4", "File too small (neither vecbin64 nor raw12)"),
+        "zero_dim.raw12": (struct.pack("<III", 5, 0, 0) + b"\0" * 64, "raw12 header invalid (count/dim == 0)"),
+        "short.raw12": (struct.pack("<III", 5, 0, 8) + b"\0" * 100, "raw12 header parsed but file size mismatch"),
+    }
+    for name, (blob, msg) in cases.items():
+        p = str(tmp_path / name)
+        open(p, "wb").write(blob)
+        r = subprocess.run([os.path.join(BIN, "nvdb_search"), p, files["q"], "3"], capture_output=True, text=True)
+        assert r.returncode != 0 and msg in r.stderr, (name, r.returncode, r.stderr[-300:])
+        if po.Reference.available():
+            ref = subprocess.run([os.path.join(po.Reference().bin, "nvdb_search"), p, files["q"], "3"], capture_output=True, text=True)
+            assert ref.returncode == r.returncode and msg in ref.stderr, (name, ref.returncode, ref.stderr[-300:])
+
+
 def test_cpu_modes_under_address_and_ub_sanitizers(files, golden, tmp_path):
     """The host layer (loader, SIMD dots, top-k buffers, the four CPU threadings, converters, gt writer) built with
     -fsanitize=address,undefined must run clean and still produce the reference's bytes.  CPU build only."""
