@@ -687,3 +687,12 @@ def test_adopted_corpus_and_device_buffers(oracle, tag):
         oid, od = oracle.refine(base, po.DT_F16 if tag == "f16" else po.DT_F32, queries, cand, k, mode=0)
         assert np.array_equal(t_oi.cpu().numpy().view(np.uint32), oid) and np.array_equal(t_od.cpu().numpy().view(np.uint32), od.view(np.uint32))
         ctx.close()
+
+
+def test_randomised_cross_check():
+    """tools_dev/fuzz.py: 40 random (n, dim, dtype, nq, k, options) cases; the automatic path must equal the exact path
+    (ids and score bits), and both the oracle on a few queries per case."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools_dev", "fuzz.py"), "7", "40"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
