@@ -16,6 +16,7 @@
 //     finished its stream (scatter_own_log).  Nothing else is written: the B x N score matrix never exists.
 //
 // Kernels: filter_f16_m16_kernel (production fp16, v_mfma_f32_16x16x32_f16; MB/NQB pick the tile shape),
+// filter_f16_k2_kernel (1536 < DIM <= 3072: a tile streamed as two half-K stages),
 // filter_f16_kernel (32x32x16 build: batches <= 128, the bootstrap build VAR 7, timing ablations),
 // filter_i8w_kernel (int8 two-stage: hi plane always, lo plane on demand), filter_i8_kernel (int8 two-plane:
 // bootstrap build, A/B reference), prep_q16 / prep_q8 (query scaling, error bounds), shadow / generator / norm kernels.
@@ -679,6 +680,152 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
     if (wave == 0 && lane == 0) {
       uint64_t* out = reinterpret_cast<uint64_t*>(prog + static_cast<uint64_t>(gridDim.x) * 8) + static_cast<uint64_t>(blockIdx.x) * 2;
       out[0] = dc; out[1] = dr;
+    }
+  }
+  if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(myprog + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  scatter_own_log(mylog, wcnt, sa, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1536 < DIM <= 3072: the K-split build.  A wave cannot hold more than 384 registers of B fragments, so it keeps ONE
+// 16-query block (DIM/8 registers) and a 16-row tile is streamed as two stages, one per half of K (each again
+// <= 48 KB); the accumulators live across the two stages and the threshold test runs after the second.  One MFMA per
+// A fragment read: LDS-bound at about half the MFMA rate of the 768 build, 64 queries per workgroup -- still far from
+// the fp32 VALU path these dims would otherwise take.  Same logging / scatter / rendezvous as filter_f16_m16_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int DIM, bool SYNC = false>
+__global__ __launch_bounds__(256, 1) void filter_f16_k2_kernel(
+    const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
+    uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
+    const float* __restrict__ qinv, Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t* __restrict__ prog,
+    uint32_t sync_mask, uint32_t sync_lead) {
+  constexpr int RING = 6;
+  constexpr int DIMS = DIM / 2;                    // dims per stage
+  constexpr int KS = DIMS / 32;                    // k-steps of 32 per stage
+  constexpr int ROW_BYTES = DIM * 2, SROW = DIMS * 2;
+  constexpr int TROWS = 16;
+  constexpr int STAGE_BYTES = TROWS * SROW;
+  constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / 4;
+  constexpr int CPR = SROW / 16;                   // 16-byte chunks per stage row
+  constexpr int NFRAG = 2 * KS, NFRAG_A = NFRAG < 64 ? NFRAG : 64, NFRAG_V = NFRAG - NFRAG_A;
+  static_assert(DIMS % 128 == 0 && PIECES % 4 == 0 && KS % PPW == 0 && NFRAG * 4 <= 384 && STAGE_BYTES * FILTER_STAGES <= 160 * 1024, "shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x15 = lane & 15, g4 = lane >> 4;
+  const uint32_t wave_gid = blockIdx.x * 4 + wave;
+
+  const uint32_t nwg = gridDim.x, b = blockIdx.x;
+  const uint32_t S = nwg / QT;
+  uint32_t stream, qt;
+  if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
+  else { qt = b % QT; stream = b / QT; }
+  const uint32_t tiles_total = (row_hi - row_lo) / TROWS;
+  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
+  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const uint32_t NT = t_hi - t_lo;
+  if (NT == 0) return;
+
+  // B fragment f = kh*KS + s: K-half kh, k-step s; lane (x15,g4) holds q16[query x15][kh*DIMS + 32 s + 8 g4 .. +8]
+  const uint32_t qbase = qt * 64u + wave * 16u;
+  float4_t bqa[NFRAG_A];
+  float4_t bqv[NFRAG_V > 0 ? NFRAG_V : 1];
+#pragma unroll
+  for (int f = 0; f < NFRAG; ++f) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(q16 + static_cast<uint64_t>(qbase + x15) * DIM + 32 * f + 8 * g4);
+    if (f < NFRAG_A) bqa[f] = v; else bqv[f - NFRAG_A] = v;
+  }
+#pragma unroll
+  for (int f = 0; f < NFRAG_A; ++f) asm volatile("" ::"a"(bqa[f]));
+#pragma unroll
+  for (int f = 0; f < NFRAG_V; ++f) asm volatile("" ::"v"(bqv[f]));
+  const uint32_t qid = qbase + x15;
+  const bool real = qid < nq;
+  float thr_s = real ? thr[qid] * qscale[qid] : __builtin_huge_valf();
+  float inv_s = real ? qinv[qid] : 0.f;
+  asm volatile("" ::"v"(thr_s), "v"(inv_s));
+  const bool wave_has_queries = qbase < nq;
+
+  uint32_t src_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const uint32_t P = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
+    const uint32_t r = P / CPR, cpos = P % CPR;
+    src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
+  }
+  const uint32_t a16 = static_cast<uint32_t>(x15) * SROW + ((static_cast<uint32_t>(g4) ^ static_cast<uint32_t>(x15)) << 4);
+
+  const char* gbase = reinterpret_cast<const char*>(rows);
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
+  const uint32_t g_lo = row_lo / TROWS + t_lo;
+  auto tile_phys = [&](uint32_t t_rel) -> uint32_t { return perm_tile(g_lo + (t_rel < NT ? t_rel : NT - 1), sa); };
+  auto stage_ptr = [&](uint32_t t_rel, int kh) -> const char* {
+    return gbase + static_cast<uint64_t>(tile_phys(t_rel)) * TROWS * ROW_BYTES + kh * SROW;
+  };
+  auto issue_piece = [&](const char* src, uint32_t buf, int i) {
+    glds16(src_off[i], src, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
+  };
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) issue_piece(stage_ptr(0, 0), 0, i);
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) issue_piece(stage_ptr(0, 1), 1, i);
+
+  constexpr int PIECE_EVERY = KS / PPW;
+  uint32_t wcnt = 0;
+  Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
+  uint32_t* myprog = prog + static_cast<uint64_t>(stream) * 8;
+  uint32_t sync_strikes = 0;
+  for (uint32_t t = 0; t < NT; ++t) {
+    if constexpr (SYNC) {
+      if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(myprog, qt, t, sync_lead, sync_strikes, lane);
+    }
+    float4_t acc;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const uint32_t st = 2 * t + kh;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const char* next_src = stage_ptr(t + 1, kh);               // stage st+2 = the same half of the next tile
+      const uint32_t next_buf = (st + 2) % FILTER_STAGES;
+      const char* stage = smem + (st % FILTER_STAGES) * STAGE_BYTES;
+      if (!wave_has_queries) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) issue_piece(next_src, next_buf, i);
+        continue;
+      }
+      auto read_a = [&](int s) -> float4_t {
+        return *reinterpret_cast<const float4_t*>(stage + (a16 ^ ((s & 3) << 6)) + (s >> 2) * 256);
+      };
+      float4_t ar[RING];
+#pragma unroll
+      for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(s);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s + RING - 1 < KS) ar[(s + RING - 1) % RING] = read_a(s + RING - 1);
+        const float4_t a = ar[s % RING];
+        const int f = kh * KS + s;
+        if (f == 0) NVDB_MFMA16_ZERO_A(acc, a, bqa[0]);
+        else if (f < NFRAG_A) NVDB_MFMA16_ACC_A(acc, a, bqa[f < NFRAG_A ? f : 0]);
+        else NVDB_MFMA16_ACC_V(acc, a, bqv[f >= NFRAG_A ? f - NFRAG_A : 0]);
+        if (s % PIECE_EVERY == PIECE_EVERY - 1) issue_piece(next_src, next_buf, s / PIECE_EVERY);
+      }
+    }
+    if (!wave_has_queries) continue;
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
+    const float m = vmax3(vmax3(acc[0], acc[1], acc[2]), acc[3], acc[3]);
+    if (__builtin_amdgcn_ballot_w64(m - thr_s >= 0.f)) {
+      const uint32_t row0 = tile_phys(t) * TROWS;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[r];
+        const bool hit = v >= thr_s;
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(hit);
+        if (mm) {
+          const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(mm & ((1ull << lane) - 1ull)));
+          if (hit && idx < FILTER_LOGCAP) mylog[idx] = Hit{v * inv_s, row0 + 4 * g4 + r, qid, 0u};
+          wcnt += static_cast<uint32_t>(__builtin_popcountll(mm));
+        }
+      }
     }
   }
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(myprog + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

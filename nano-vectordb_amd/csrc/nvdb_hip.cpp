@@ -150,11 +150,12 @@ void free_corpus(nvdb_hip_ctx* c) {
 }
 
 // dims the fp16 MFMA kernels are instantiated for: multiples of 128 up to 768 (64 queries per wave: their fragments fill
-// 384 registers at 768), and 1024 / 1536 on the 16-row-tile build (32 queries per wave)
+// 384 registers at 768), 1024 / 1536 on the 16-row-tile build (32 queries per wave), 2048 / 3072 on the K-split build
+// (16 queries per wave, a tile streamed as two half-K stages)
 constexpr uint32_t PROG_SLOTS = 16;   // filter launches per search whose rendezvous counters the init kernel pre-clears
 
-bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128 || dim == 1024 || dim == 1536; }
-constexpr uint32_t F16_FILTER_MAX_DIM = 1536;
+bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128 || dim == 1024 || dim == 1536 || dim == 2048 || dim == 3072; }
+constexpr uint32_t F16_FILTER_MAX_DIM = 3072;
 constexpr uint32_t I8W_TILE_ROWS = 64;                // rows per tile of the int8 two-stage kernel (two 32-row blocks)
 constexpr uint32_t PAD_ROWS = 64;                     // zero rows every library-owned corpus / shadow is padded with: the largest tile
 bool i8_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 256; }   // int8 rows: stride % 256 == 0
@@ -402,6 +403,36 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
   return NVDB_OK;
 }
 
+// dims 2048 / 3072: K-split build, 16-row tiles in two half-K stages, 16 queries per wave, 64 per workgroup
+template <int DIM>
+nvdb_status launch_filter_k2_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT, uint32_t cap) {
+  constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * 16 * (DIM / 2) * 2;
+  uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
+  if (nwg == 0) nwg = QT;
+  nvdb_status st;
+  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+  const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+  uint32_t* prog = nullptr;
+  if (sync && (st = next_prog_region(c, s, nwg, &prog))) return st;
+#define NVDB_K2_LAUNCH(SYNCV)                                                                                                   \
+  {                                                                                                                             \
+    const void* fn = reinterpret_cast<const void*>(filter_f16_k2_kernel<DIM, SYNCV>);                                           \
+    if (!c->lds_attr_set.count(fn)) {                                                                                           \
+      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
+      c->lds_attr_set.insert(fn);                                                                                               \
+    }                                                                                                                           \
+    hipExtLaunchKernelGGL((filter_f16_k2_kernel<DIM, SYNCV>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0,      \
+                          filter_rows_f16(c), row_lo, row_hi, static_cast<const _Float16*>(c->q16.p), nq, QT,                   \
+                          static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p),                          \
+                          static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, 16), prog, \
+                          static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));               \
+  }
+  if (sync) NVDB_K2_LAUNCH(true) else NVDB_K2_LAUNCH(false)
+#undef NVDB_K2_LAUNCH
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
 // dims 1024 / 1536: 16-row tiles, 32 queries per wave (MB = 1, NQB = 2), 128 queries per workgroup
 template <int DIM>
 nvdb_status launch_filter_k_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT, uint32_t cap) {
@@ -585,6 +616,8 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
     if (c->fdim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 filter kernel: unsupported dim");
   }
+  if (c->fdim == 2048) return launch_filter_k2_dim<2048>(c, s, row_lo, row_hi, nq, QT, cap);
+  if (c->fdim == 3072) return launch_filter_k2_dim<3072>(c, s, row_lo, row_hi, nq, QT, cap);
   if (c->fdim == 1024) return launch_filter_k_dim<1024>(c, s, row_lo, row_hi, nq, QT, cap);
   if (c->fdim == 1536) return launch_filter_k_dim<1536>(c, s, row_lo, row_hi, nq, QT, cap);
 #define NVDB_FILTER_DIM(D) if (c->fdim == D) return nb == 1 ? launch_filter_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, cap)
@@ -605,12 +638,13 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t n = static_cast<uint32_t>(c->n);
   int path = force_path ? force_path : static_cast<int>(c->opt_path);
   if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
-  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 1536 or an int8 corpus with dim <= 768");
+  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 3072 or an int8 corpus with dim <= 768");
 
   uint32_t cap = cap_override ? cap_override : c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : std::max<uint32_t>(c->cap_hint, nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
   if (cap < 4 * k_eff) cap = std::min<uint32_t>(SELECT_MAX_CAP, 4 * k_eff);
-  const uint32_t QPB = 128u * filter_nb(c, nq);              // queries per filter workgroup
+  // queries per filter workgroup: 256 / 128, or 64 on the K-split build (dims > 1536)
+  const uint32_t QPB = (c->dtype != NVDB_DTYPE_I8 && c->fdim > 1536) ? 64u : 128u * filter_nb(c, nq);
   const uint32_t QT = (nq + QPB - 1) / QPB;
   const uint32_t nq_pad = QT * QPB;
 

@@ -339,10 +339,12 @@ def test_filter_path_on_zero_padded_shadow_for_odd_dims(ctx, oracle, tag, d, nq)
     _check_against_oracle(oracle, base, po.DT_F16 if tag == "f16" else po.DT_F32, None, queries, res[2][0], res[2][1], k, f"pad/{tag}/d{d}")
 
 
-@pytest.mark.parametrize("tag,d,nq", [("f16", 1536, 300), ("f16", 1024, 64), ("f16", 1000, 130), ("f32", 1536, 40), ("f16", 1280, 33)])
+@pytest.mark.parametrize("tag,d,nq", [("f16", 1536, 300), ("f16", 1024, 64), ("f16", 1000, 130), ("f32", 1536, 40), ("f16", 1280, 33),
+                                      ("f16", 3072, 200), ("f16", 2048, 70), ("f16", 2500, 130), ("f32", 3072, 20), ("f16", 1600, 600)])
 def test_filter_path_for_dims_up_to_1536(ctx, oracle, tag, d, nq):
-    """768 < dim <= 1536: the 16-row-tile build of the fp16 kernel (32 queries per wave; dims other than 1024 / 1536
-    through the zero-padded shadow).  Same exact rescore, so ids and score bits match the CPU path."""
+    """768 < dim <= 1536: the 16-row-tile build of the fp16 kernel (32 queries per wave); 1536 < dim <= 3072: the K-split
+    build (16 queries per wave, a tile streamed as two half-K stages); other dims through the zero-padded shadow.  Same
+    exact rescore, so ids and score bits match the CPU path."""
     n, k = 60000 + 5, 10
     dt = nvdb_amd.DT_F16 if tag == "f16" else nvdb_amd.DT_F32
     ctx.generate_corpus(SEED + 90, n, d, dt)
