@@ -489,8 +489,10 @@ __device__ __forceinline__ void sibling_rendezvous(uint32_t* myprog, uint32_t qt
 // MB x NQB = 16-row blocks per tile x 16-query blocks per wave: 2 x 4 (32-row tiles, 64 queries per wave) for
 // DIM <= 768; 1 x 2 (16-row tiles, 32 queries per wave) for DIM up to 1536 -- the wave's B fragments are NQB*DIM/8
 // registers either way (384 at the two corners), and a stage stays 48 KB.
-template <int DIM, int RING = 6, bool SYNC = false, bool STAMP = false, int VAR = 0, int MB = 2, int NQB = 4>
-__global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
+// WPB = waves per workgroup: 4 (one per SIMD, 512 registers each) or 8 (two per SIMD, 256 registers each, NQB = 2:
+// the second wave of a SIMD fills the gaps the first leaves at tile boundaries; twice the LDS reads per MFMA)
+template <int DIM, int RING = 6, bool SYNC = false, bool STAMP = false, int VAR = 0, int MB = 2, int NQB = 4, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, 1) void filter_f16_m16_kernel(
     const _Float16* __restrict__ rows, uint32_t row_lo, uint32_t row_hi, const _Float16* __restrict__ q16,
     uint32_t nq, uint32_t QT, const float* __restrict__ thr, const float* __restrict__ qscale,
     const float* __restrict__ qinv, Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t* __restrict__ prog,
@@ -499,17 +501,18 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
   constexpr int ROW_BYTES = DIM * 2;
   constexpr int TROWS = 16 * MB;                   // corpus rows per tile
   constexpr int STAGE_BYTES = TROWS * ROW_BYTES;
-  constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / 4;
+  constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / WPB;
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
-  constexpr int NFRAG = NQB * KS, NFRAG_A = NFRAG < 64 ? NFRAG : 64, NFRAG_V = NFRAG - NFRAG_A;
+  constexpr int NFRAG = NQB * KS, AMAX = WPB == 8 ? 32 : 64;      // two waves per SIMD: 128 AGPRs + 128 VGPRs each
+  constexpr int NFRAG_A = NFRAG < AMAX ? NFRAG : AMAX, NFRAG_V = NFRAG - NFRAG_A;
   constexpr int NREAD = MB * KS;                   // A fragments per tile (MB row blocks x KS)
-  static_assert(DIM % 128 == 0 && PIECES % 4 == 0 && NREAD % PPW == 0, "shape");
+  static_assert(DIM % 128 == 0 && PIECES % WPB == 0 && NREAD % PPW == 0 && (WPB == 4 || WPB == 8), "shape");
   static_assert((MB == 1 || MB == 2 || MB == 4) && (NQB == 2 || NQB == 4) && NQB * KS * 4 <= 384 && STAGE_BYTES * FILTER_STAGES <= 160 * 1024, "registers / LDS");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int x15 = lane & 15, g4 = lane >> 4;
-  const uint32_t wave_gid = blockIdx.x * 4 + wave;
+  const uint32_t wave_gid = blockIdx.x * WPB + wave;
 
   const uint32_t nwg = gridDim.x, b = blockIdx.x;
   const uint32_t S = nwg / QT;
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_m16_kernel(
 
   // B fragment f = nb*KS + s: query block nb (16 queries), k-step s; lane (x15,g4) holds
   // q16[query x15 of the block][32 s + 8 g4 .. +8]
-  const uint32_t qbase = qt * (64u * NQB) + wave * (16u * NQB);
+  const uint32_t qbase = qt * (16u * NQB * WPB) + wave * (16u * NQB);
   float4_t bqa[NFRAG_A];
   float4_t bqv[NFRAG_V > 0 ? NFRAG_V : 1];
 #pragma unroll
