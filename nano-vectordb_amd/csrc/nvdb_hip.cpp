@@ -1284,6 +1284,19 @@ nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* c, int variant, uint32_t nq, floa
       case 15: NVDB_CLK_LAUNCH(15) break;
       case 16: NVDB_CLK_LAUNCH(16) break;
       case 17: NVDB_CLK_LAUNCH(17) break;
+      case 20: {                                  // the 8-wave production build (two waves per SIMD, 32 queries each), stamped
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_f16_m16_kernel<768, 4, true, true, 0, 2, 2, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 8 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+        for (uint32_t r = 0; r < burst; ++r) {
+          HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, prog_bytes, c->stream));
+          filter_f16_m16_kernel<768, 4, true, true, 0, 2, 2, 8><<<nwg, 512, lds, c->stream>>>(
+              static_cast<const _Float16*>(c->rows), 0, n_al, static_cast<const _Float16*>(c->q16.p), nq, QT,
+              static_cast<const float*>(inf.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
+              static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap), static_cast<uint32_t*>(c->prog.p),
+              static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));
+        }
+      } break;
       default: return fail(c, NVDB_ERR_INVALID, "debug: unknown variant");
     }
     HIPCHK(c, hipGetLastError());

@@ -14,13 +14,13 @@ lib = nvdb_amd.load_library()
 for nq in (1024, 512):
     q = nvdb_amd.synth_rows_f32(1, 0, nq, 768)
     ctx.set_option("path", 2); ctx.search_batch(q, 10)
-    for var, name in ((0, "production loop"), (1, "no LDS-DMA"), (5, "no LDS reads"), (15, "bare MFMA stream"), (16, "bare, no epilogue"), (17, "bare, no epilogue, no barrier"), (0, "production loop")):
+    for var, name in ((20, "8-wave build (default at d=768)"), (0, "4-wave build"), (1, "no LDS-DMA"), (5, "no LDS reads"), (15, "bare MFMA stream"), (16, "bare, no epilogue"), (17, "bare, no epilogue, no barrier"), (0, "4-wave build"), (20, "8-wave build (default at d=768)")):
         out = (C.c_float * 4)()
         st = lib.nvdb_hip_debug_clock(ctx.h, var, nq, secs, out)
         assert st == 0, lib.nvdb_hip_last_error(ctx.h)
         ms, med, lo, hi = out[0], out[1], out[2], out[3]
         tf = 2.0 * nq * n * 768 / ms / 1e9
-        mfma_cycles = (n / 32) * ((nq + 255) // 256) / 256.0 * 3072        # per SIMD: tiles per workgroup x 192 MFMAs x 16 cycles
+        mfma_cycles = (n / 32) * ((nq + 255) // 256) / 256.0 * 3072        # per SIMD: tiles per workgroup x 192 MFMAs x 16 cycles (4-wave: one wave, 8-wave: two waves x 96)
         busy = mfma_cycles / (ms * 1e-3 * med * 1e9)
         print(f"nq={nq} [{name}] whole-corpus launch {ms:.3f} ms = {tf:.0f} TFLOP/s; in-kernel clock median {med:.3f} GHz (min {lo:.3f}, max {hi:.3f}); "
               f"MFMA pipe busy {busy:.3f} of the cycles at that clock; peak at that clock {2.5e3 * med / 2.4:.0f} TFLOP/s -> {tf / (2.5e3 * med / 2.4):.3f}", flush=True)
