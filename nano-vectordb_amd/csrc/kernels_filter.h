@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_f16_m16_kernel(
   constexpr int NFRAG_A = NFRAG < AMAX ? NFRAG : AMAX, NFRAG_V = NFRAG - NFRAG_A;
   constexpr int NREAD = MB * KS;                   // A fragments per tile (MB row blocks x KS)
   static_assert(DIM % 128 == 0 && PIECES % WPB == 0 && NREAD % PPW == 0 && (WPB == 4 || WPB == 8), "shape");
-  static_assert((MB == 1 || MB == 2 || MB == 4) && (NQB == 2 || NQB == 4) && NQB * KS * 4 <= 384 && STAGE_BYTES * FILTER_STAGES <= 160 * 1024, "registers / LDS");
+  static_assert((MB == 1 || MB == 2 || MB == 4) && (NQB == 1 || NQB == 2 || NQB == 4) && NQB * KS * 4 <= 384 && STAGE_BYTES * FILTER_STAGES <= 160 * 1024, "registers / LDS");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_f16_m16_kernel(
       dmax[nb] = m - thr_s[nb];                      // >= 0 iff m >= thr (a difference of floats never rounds across 0)
     }
     const bool any = (NQB == 4 ? vmax3(vmax3(dmax[0], dmax[1], dmax[NQB / 2]), dmax[NQB - 1], dmax[NQB - 1])
-                               : vmax3(dmax[0], dmax[1], dmax[1])) >= 0.f;
+                               : NQB == 2 ? vmax3(dmax[0], dmax[NQB - 1], dmax[NQB - 1]) : dmax[0]) >= 0.f;
     if (__builtin_amdgcn_ballot_w64(any)) {
       const uint32_t row0 = tile_phys(t) * TROWS;
 #pragma unroll

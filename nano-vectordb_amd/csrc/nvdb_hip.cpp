@@ -474,6 +474,21 @@ nvdb_status launch_filter_k_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo,
                           static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, 16), prog, \
                           static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));               \
   }
+  if (sync && c->opt_waves8) {
+    // two waves per SIMD: 8 waves x 16 queries (DIM/8 <= 192 registers of fragments per wave)
+    if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 8 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+    const void* f8 = reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM, 4, true, false, 0, 1, 1, 8>);
+    if (!c->lds_attr_set.count(f8)) {
+      HIPCHK(c, hipFuncSetAttribute(f8, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      c->lds_attr_set.insert(f8);
+    }
+    hipExtLaunchKernelGGL((filter_f16_m16_kernel<DIM, 4, true, false, 0, 1, 1, 8>), dim3(nwg), dim3(512), lds, s, c->launch_e0, c->launch_e1, 0,
+                          filter_rows_f16(c), row_lo, row_hi, static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
+                          static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p),
+                          scatter_args(c, cap, 16), prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));
+    HIPCHK(c, hipGetLastError());
+    return NVDB_OK;
+  }
   if (sync) NVDB_K_LAUNCH(true) else NVDB_K_LAUNCH(false)
 #undef NVDB_K_LAUNCH
   HIPCHK(c, hipGetLastError());
