@@ -698,3 +698,12 @@ def test_randomised_cross_check():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools_dev", "fuzz.py"), "7", "40"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_randomised_refine_check():
+    """tools_dev/fuzz_refine.py: 30 random (n, dim, dtype, Q, R, K) refine cases with invalid / out-of-range / duplicate
+    candidate ids on both refine kernels; ids and distance bits must equal the oracle's restated kernel order."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools_dev", "fuzz_refine.py"), "5", "30"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
