@@ -162,9 +162,11 @@ nvdb_status nvdb_hip_merge_topk_strided_dev(nvdb_hip_ctx* ctx, const uint64_t* d
 nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint32_t nshards, uint32_t nq,
                                  uint32_t k, uint64_t* out_ids, float* out_scores);
 
-/* Tunables: "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "chunk_growth", "cand_cap", "min_filter_batch",
- * "time_kernels" (1: bracket every launch of the dominant kernel with hipEvents on its stream).
- * Unknown key -> NVDB_ERR_INVALID. */
+/* Tunables (defaults are what bench.py measures; the table with meanings is in INTEGRATION.md section 4b):
+ * "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "chunk_growth", "cand_cap", "min_filter_batch", "mfma_boot",
+ * "mfma16", "waves8", "sibling_sync", "sync_every", "sync_lead", "tile_permute", "f32_shadow" (set before the upload),
+ * "i8_wide", "rescore8", "refine_v2", "time_kernels" (1: start / stop events attached to every launch of the dominant
+ * kernel).  Unknown key -> NVDB_ERR_INVALID. */
 nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* ctx, const char* key, int64_t value);
 
 /* With "time_kernels" = 1: sum of the hipEvent durations of the dominant (filter) kernel's launches
