@@ -25,19 +25,13 @@
 #include <unordered_set>
 #include <vector>
 
+#include "nvdb/cpu_refine.h"
 #include "nvdb/cuda_refine.h"
 #include "nvdb/flat_index_hip.h"
 #include "nvdb/vector_dataset.h"
 
 static int env_int(const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; }
 static std::string env_str(const char* k, const char* d) { const char* v = std::getenv(k); return v ? v : d; }
-
-static float half_to_float(uint16_t v) {
-  uint32_t s = (v & 0x8000u) << 16, e = (v >> 10) & 31, m = v & 1023, o;
-  if (e == 0) { if (!m) o = s; else { int x = -14; while (!(m & 1024)) { m <<= 1; --x; } o = s | (uint32_t(x + 127) << 23) | ((m & 1023) << 13); } }
-  else if (e == 31) o = s | 0x7F800000u | (m << 13); else o = s | ((e + 112) << 23) | (m << 13);
-  float f; std::memcpy(&f, &o, 4); return f;
-}
 
 int main(int argc, char** argv) {
   if (argc < 4) { std::cerr << "Usage: nvdb_cuda_refine_eval <base.vecbin> <query.vecbin> <k>\n"; return 1; }
@@ -81,23 +75,19 @@ int main(int argc, char** argv) {
     }
   }
 
-  // ---- CPU refine (reference arithmetic: double accumulation, apps/nvdb_ivf_eval.cpp:232-240) ---------
+  // ---- CPU refine: nvdb::refine_topk_l2_ids (double accumulation over base_row_to_f32 rows; reference
+  //      apps/nvdb_ivf_eval.cpp:232-240, 278-307, include/nvdb/to_f32_row.h:10-34) -----------------------------
   std::vector<uint32_t> cpu_ids(static_cast<size_t>(Q) * k, 0xFFFFFFFFu);
   const auto tc0 = std::chrono::steady_clock::now();
 #pragma omp parallel for schedule(dynamic, 8)
   for (int64_t qi = 0; qi < static_cast<int64_t>(Q); ++qi) {
-    const float* qv = query.vector_ptr_f32(qi);
-    std::vector<std::pair<float, uint32_t>> best;
+    std::vector<int64_t> c64(R);
     for (uint32_t r = 0; r < R; ++r) {
       const uint32_t id = cand[qi * R + r];
-      if (id == 0xFFFFFFFFu || id >= N) continue;
-      double s = 0.0;
-      if (base.dtype() == 1) { const float* x = base.vector_ptr_f32(id); for (uint32_t j = 0; j < d; ++j) { const double t = double(qv[j]) - double(x[j]); s += t * t; } }
-      else { const uint16_t* x = base.vector_ptr_f16(id); for (uint32_t j = 0; j < d; ++j) { const double t = double(qv[j]) - double(half_to_float(x[j])); s += t * t; } }
-      best.emplace_back(static_cast<float>(s), id);
+      c64[r] = (id == 0xFFFFFFFFu || id >= N) ? -1 : static_cast<int64_t>(id);      // the stage-A "no candidate" marker (:513-516)
     }
-    std::sort(best.begin(), best.end());
-    for (int j = 0; j < k && j < static_cast<int>(best.size()); ++j) cpu_ids[qi * k + j] = best[j].second;
+    const std::vector<uint64_t> best = nvdb::refine_topk_l2_ids(base, query.vector_ptr_f32(qi), c64.data(), static_cast<int>(R), static_cast<uint32_t>(k));
+    for (size_t j = 0; j < best.size(); ++j) cpu_ids[qi * k + j] = static_cast<uint32_t>(best[j]);
   }
   const double cpu_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
 

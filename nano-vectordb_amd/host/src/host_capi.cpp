@@ -1,0 +1,62 @@
+// host_capi.cpp -- extern "C" test hooks onto the C++ host layer (lib/libnvdb_host_capi.so).
+//
+// NOT the drop-in boundary (that is include/nvdb_hip.h) and not linked into the tools: it exists so that the CPU
+// tests can call the nvdb:: host functions directly through ctypes and compare them with the reference goldens --
+// the dot kernels on both dispatch branches, f16_to_f32_scalar / base_row_to_f32 (reference f16_scalar.h,
+// to_f32_row.h) and the CPU refine (apps/nvdb_ivf_eval.cpp:232-240, 278-307).
+#include <cstdint>
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "nvdb/cpu_refine.h"
+#include "nvdb/f16_scalar.h"
+#include "nvdb/simd_dot.h"
+#include "nvdb/to_f32_row.h"
+#include "nvdb/vector_dataset.h"
+
+static std::string g_err;
+
+extern "C" {
+
+const char* nvdb_host_last_error() { return g_err.c_str(); }
+int nvdb_host_simd_available() { return nvdb::simd_dot_available() ? 1 : 0; }
+void nvdb_host_set_force_scalar(int v) { nvdb::set_force_scalar(v != 0); }
+float nvdb_host_dot_f32(const float* a, const float* b, uint32_t dim) { return nvdb::dot_f32(a, b, dim); }
+float nvdb_host_dot_f32_f16base(const float* q, const uint16_t* x, uint32_t dim) { return nvdb::dot_f32_f16base(q, x, dim); }
+float nvdb_host_dot_f32_f16base_scalar(const float* q, const uint16_t* x, uint32_t dim) { return nvdb::dot_f32_f16base_scalar(q, x, dim); }
+float nvdb_host_dot_f32_i8base(const float* q, const int8_t* x, uint32_t dim, float scale) { return nvdb::dot_f32_i8base(q, x, dim, scale); }
+
+void nvdb_host_f16_to_f32(const uint16_t* h, uint64_t n, float* out) {
+  for (uint64_t i = 0; i < n; ++i) out[i] = nvdb::f16_to_f32_scalar(h[i]);
+}
+
+void* nvdb_host_dataset_open(const char* path) {
+  try {
+    auto* ds = new nvdb::VectorDataset();
+    ds->load(path);
+    return ds;
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void nvdb_host_dataset_close(void* h) { delete static_cast<nvdb::VectorDataset*>(h); }
+
+int nvdb_host_base_row_to_f32(void* h, uint64_t row, float* out) {
+  try { nvdb::base_row_to_f32(*static_cast<nvdb::VectorDataset*>(h), row, out); return 0; }
+  catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+// out_ids[k] padded with UINT64_MAX, out_dist[k] (optional) padded with +inf; returns the number of results
+int nvdb_host_refine_topk_l2(void* h, const float* q, const int64_t* cand, int cand_k, uint32_t k, uint64_t* out_ids, float* out_dist) {
+  try {
+    std::vector<float> dist;
+    const std::vector<uint64_t> ids = nvdb::refine_topk_l2_ids(*static_cast<nvdb::VectorDataset*>(h), q, cand, cand_k, k, &dist);
+    for (uint32_t j = 0; j < k; ++j) {
+      out_ids[j] = j < ids.size() ? ids[j] : ~0ull;
+      if (out_dist) out_dist[j] = j < dist.size() ? dist[j] : __builtin_huge_valf();
+    }
+    return static_cast<int>(ids.size());
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+}  // extern "C"

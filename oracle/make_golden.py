@@ -97,5 +97,43 @@ def main():
     print(f"wrote tests/golden/flat_golden.npz: {len(g)} arrays, {sz} bytes")
 
 
+CONV_ROWS = (0, 1, 2, 1499, 2999)            # rows of case "main768" whose float32 widening is kept
+
+
+def main_refine_conv():
+    """tests/golden/refine_conv_golden.npz: the row conversion under the reference's CPU refine --
+    nvdb::f16_to_f32_scalar (include/nvdb/f16_scalar.h:8-38) on ALL 65 536 half bit patterns, and
+    nvdb::base_row_to_f32 (include/nvdb/to_f32_row.h:10-34) on rows of the "main768" case in each base dtype
+    (the f16 / int8 files are written by the reference's own converter tools, as in main())."""
+    os.makedirs(OUT, exist_ok=True)
+    ref = po.Reference()
+    tmp = tempfile.mkdtemp(prefix="nvdb_golden_")
+    g = {}
+    allh, allf = np.arange(65536, dtype=np.uint16), np.empty(65536, dtype=np.float32)
+    ref.lib.ref_f16_to_f32_array(allh.ctypes.data, 65536, po._p(allf, po._f32p))      # written to memory: NaN payload bits intact
+    g["f16_to_f32_all"] = allf.view(np.uint32).copy()
+    base32, _ = make_case_inputs("main768")
+    d = base32.shape[1]
+    pb32, pb16, pb8 = (os.path.join(tmp, f"main768_{t}.vecbin") for t in ("f32", "f16", "i8"))
+    po.write_vecbin(pb32, base32, po.DT_F32)
+    ref.run_tool("nvdb_convert_f16", pb32, pb16)
+    ref.run_tool("nvdb_quantize_i8", pb32, pb8)
+    g["main768_f16_sha"] = np.frombuffer(bytes.fromhex(sha(po.read_vecbin(pb16)[0])), dtype=np.uint8)
+    b8, _, sc8 = po.read_vecbin(pb8)
+    g["main768_i8_sha"] = np.frombuffer(bytes.fromhex(sha(b8, sc8)), dtype=np.uint8)
+    g["rows"] = np.array(CONV_ROWS, dtype=np.uint64)
+    for tag, path in (("f32", pb32), ("f16", pb16), ("i8", pb8)):
+        h = ref.open(path)
+        g[f"main768_{tag}_rows_f32"] = bits(np.stack([ref.base_row_to_f32(h, r, d) for r in CONV_ROWS]))
+        ref.close(h)
+    np.savez_compressed(os.path.join(OUT, "refine_conv_golden.npz"), **g)
+    sz = os.path.getsize(os.path.join(OUT, "refine_conv_golden.npz"))
+    print(f"wrote tests/golden/refine_conv_golden.npz: {len(g)} arrays, {sz} bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "refine_conv":
+        main_refine_conv()
+    else:
+        main()
+        main_refine_conv()

@@ -290,14 +290,23 @@ float oracle_l2_f32_gpu_order(const float* q, const float* x, uint32_t dim) {
   return acc;
 }
 
-/* apps/nvdb_ivf_eval.cpp:232-240 (l2_sqr_f32) on a row widened by to_f32_row.h:10-34: double
+/* include/nvdb/to_f32_row.h:10-34 (base_row_to_f32): fp32 copied, fp16 through f16_to_f32_scalar
+ * (include/nvdb/f16_scalar.h:8-38), int8 as float(v) * scale.  PINNED: tests/golden/refine_conv_golden.npz holds the
+ * real reference's output for all 65 536 half patterns and for rows of each dtype. */
+void oracle_base_row_to_f32(const void* x, float scale, uint32_t dtype, uint32_t dim, float* out) {
+  for (uint32_t j = 0; j < dim; ++j)
+    out[j] = (dtype == 1) ? ((const float*)x)[j]
+           : (dtype == 2) ? oracle_f16_to_f32(((const uint16_t*)x)[j])
+                          : (float)((const int8_t*)x)[j] * scale;
+}
+
+/* apps/nvdb_ivf_eval.cpp:232-240 (l2_sqr_f32) on a row widened by base_row_to_f32: double
  * accumulation of (double(a)-double(b))^2, cast to float at the end. */
 float oracle_l2_cpu_double(const float* q, const void* x, uint32_t dtype, uint32_t dim) {
+  float row[dim];
+  oracle_base_row_to_f32(x, 0.f, dtype, dim, row);
   double s = 0.0;
-  for (uint32_t j = 0; j < dim; ++j) {
-    float xv = (dtype == 1) ? ((const float*)x)[j] : oracle_f16_to_f32(((const uint16_t*)x)[j]);
-    double d = (double)q[j] - (double)xv; s += d * d;
-  }
+  for (uint32_t j = 0; j < dim; ++j) { double d = (double)q[j] - (double)row[j]; s += d * d; }
   return (float)s;
 }
 

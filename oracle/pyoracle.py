@@ -113,6 +113,9 @@ class Oracle:
         for name in ("oracle_l2_f16_gpu_order",):
             getattr(L, name).restype = C.c_float
             getattr(L, name).argtypes = [_f32p, C.c_void_p, C.c_uint32]
+        L.oracle_base_row_to_f32.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, _f32p]
+        L.oracle_l2_cpu_double.restype = C.c_float
+        L.oracle_l2_cpu_double.argtypes = [_f32p, C.c_void_p, C.c_uint32, C.c_uint32]
 
     # -- conversions
     def f32_to_f16(self, x):
@@ -128,6 +131,13 @@ class Oracle:
     def f16_to_f32(self, h):
         h = np.ascontiguousarray(h, dtype=np.uint16)
         return np.array([self.lib.oracle_f16_to_f32(int(v)) for v in h.ravel()], dtype=np.float32).reshape(h.shape)
+
+    def base_row_to_f32(self, row, dtype, scale=0.0):
+        """to_f32_row.h:10-34 on one row (any dtype)."""
+        row = np.ascontiguousarray(row)
+        out = np.empty(row.shape[0], dtype=np.float32)
+        self.lib.oracle_base_row_to_f32(row.ctypes.data, float(scale), dtype, row.shape[0], _p(out, _f32p))
+        return out
 
     def quantize_i8(self, rows_f32):
         rows = np.ascontiguousarray(rows_f32, dtype=np.float32)
@@ -206,6 +216,10 @@ class Reference:
         L.ref_flat_search.argtypes = [C.c_void_p, _f32p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, _u64p, _f32p,
                                       C.POINTER(C.c_double)]
         L.ref_omp_max_threads.restype = C.c_int
+        if hasattr(L, "ref_f16_to_f32_array"):
+            L.ref_f16_to_f32_array.argtypes = [C.c_void_p, C.c_uint64, _f32p]
+            L.ref_base_row_to_f32.restype = C.c_int
+            L.ref_base_row_to_f32.argtypes = [C.c_void_p, C.c_uint64, _f32p]
         self.bin = os.path.join(HERE, "_ref", "bin")
 
     def open(self, path):
@@ -216,6 +230,12 @@ class Reference:
 
     def close(self, h):
         self.lib.ref_dataset_close(h)
+
+    def base_row_to_f32(self, h, row, dim):
+        out = np.empty(dim, dtype=np.float32)
+        if self.lib.ref_base_row_to_f32(h, row, _p(out, _f32p)) != 0:
+            raise RuntimeError(self.lib.ref_last_error().decode())
+        return out
 
     def flat_search(self, h, queries, k, mode=0, threads=0, want_results=True):
         queries = np.ascontiguousarray(queries, dtype=np.float32)

@@ -10,6 +10,7 @@
 #include "nvdb/flat_index.h"
 #include "nvdb/flat_index_omp.h"
 #include "nvdb/simd_dot.h"
+#include "nvdb/to_f32_row.h"
 #include "nvdb/topK.h"
 #include "nvdb/vector_dataset.h"
 
@@ -74,6 +75,16 @@ int ref_flat_search(void* h, const float* queries, uint32_t nq, uint32_t k, int 
     if (elapsed_ms) *elapsed_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     return got;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+// include/nvdb/f16_scalar.h:8-38 and include/nvdb/to_f32_row.h:10-34 -- the row conversion under the reference's CPU
+// refine (apps/nvdb_ivf_eval.cpp:256, 295).  Header-only in the reference; instantiated here so that goldens exist.
+// results go to memory, not through a float return value: a signalling-NaN pattern would be quieted on its way through
+// the caller's float -> double conversion, and the golden must hold the function's own bits
+void ref_f16_to_f32_array(const uint16_t* h, uint64_t n, float* out) { for (uint64_t i = 0; i < n; ++i) out[i] = nvdb::f16_to_f32_scalar(h[i]); }
+int ref_base_row_to_f32(void* h, uint64_t row, float* out) {
+  try { nvdb::base_row_to_f32(*static_cast<nvdb::VectorDataset*>(h), row, out); return 0; }
+  catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 
 int ref_omp_max_threads() {

@@ -558,7 +558,7 @@ def test_full_size_10M_properties(oracle, dtype, tag):
           rows copied back from HBM) and lists are in canonical (score desc, id asc) order;
       (b) no row of a 200K-row sample beats a query's k-th score (oracle scan of the sample);
       (c) sharding: top-k of [0,6M) merged with top-k of [6M,10M) == top-k of [0,10M);
-      (d) idempotence, and the MFMA path == the exact fp32 kernel on a subset of the batch."""
+      (d) idempotence, and the MFMA path == the exact fp32-order kernel for ALL 1024 queries of the batch."""
     n, d, nq, k = 10_000_000, 768, 1024, 10
     dt_o = po.DT_F16 if dtype == nvdb_amd.DT_F16 else po.DT_I8
     ctx = nvdb_amd.HipContext(0)
@@ -589,10 +589,11 @@ def test_full_size_10M_properties(oracle, dtype, tag):
     # (d) idempotence + exact kernel on a subset
     ids2, sc2 = ctx.search_batch(queries, k)
     assert np.array_equal(ids, ids2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
-    ctx.set_option("path", 1)
-    ide, sce = ctx.search_batch(queries[:8], k)
+    ctx.set_option("path", 1)                                 # ALL 1024 queries on the exact fp32-order kernel (~0.8 s)
+    ide, sce = ctx.search_batch(queries, k)
+    assert ctx.stats()["path"] == 1
     ctx.set_option("path", 0)
-    assert np.array_equal(ide, ids[:8]) and np.array_equal(sce.view(np.uint32), sc[:8].view(np.uint32))
+    assert np.array_equal(ide, ids) and np.array_equal(sce.view(np.uint32), sc.view(np.uint32))
     ctx.close()
     # (c)
     parts = []
@@ -603,6 +604,155 @@ def test_full_size_10M_properties(oracle, dtype, tag):
         c.close()
     mi, ms = nvdb_amd.merge_topk_host(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
     assert np.array_equal(mi, ids) and np.array_equal(ms.view(np.uint32), sc.view(np.uint32))
+
+
+def _rescore_returned_rows(oracle, ctx, queries, ids, sc, d, every):
+    """(a) of the full-size properties: every `every`-th query's returned scores are, bit for bit, the reference CPU
+    score (oracle dot, simd_dot.cpp:102-124) of the returned rows copied back from HBM."""
+    base = ctx.corpus_info()["row_base"]
+    for qi in range(0, len(queries), every):
+        for j in range(ids.shape[1]):
+            row, _ = ctx.download_rows(int(ids[qi, j]) - base, 1)
+            s = oracle.lib.oracle_dot_f32_f16base(po._p(queries[qi], po._f32p), row.ctypes.data, d)
+            assert np.float32(s).view(np.uint32) == sc[qi, j].view(np.uint32), (qi, j)
+
+
+def test_full_size_100M_properties(oracle):
+    """BASELINE configs[3]: fp16, N = 100M, d = 768, B = 1024, k = 10 -- the whole corpus (153.6 GB) resident on ONE
+    GPU, and the same rows as eight 12.5M-row shards (what each of 8 GPUs holds) merged on the device.
+      (a) returned scores == oracle dot of the returned rows (bits), lists canonical, ids distinct and < N;
+      (b) MFMA filter path == exact fp32-order kernel (src/flat_index.cpp:16-48 semantics) for ALL 1024 queries;
+      (c) eight shards generated one after another with their global row base, each searched, lists merged with
+          nvdb_hip_merge_topk_dev == the unsharded answer bit for bit (ids and scores);
+      (d) no row of a 200K-row sample from the last 4 GiB of the corpus beats a query's k-th score."""
+    import torch
+    n, d, nq, k, shards = 100_000_000, 768, 1024, 10, 8
+    ctx = nvdb_amd.HipContext(0)
+    ctx.generate_corpus(SEED, n, d, nvdb_amd.DT_F16)
+    queries = nvdb_amd.synth_rows_f32(SEED + 1, 0, nq, d)
+    ids, sc = ctx.search_batch(queries, k)
+    st = ctx.stats()
+    assert st["path"] == 2 and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    assert ids.shape == (nq, k) and int(ids.max()) < n
+    assert (ids > 2**32 // 1536).any() and (ids > 90_000_000).any()   # results from beyond 4 GiB and beyond 128 GiB of row offsets
+    _rescore_returned_rows(oracle, ctx, queries, ids, sc, d, every=97)
+    assert np.all((sc[:, :-1] > sc[:, 1:]) | ((sc[:, :-1] == sc[:, 1:]) & (ids[:, :-1] < ids[:, 1:])))
+    assert all(len(set(r.tolist())) == k for r in ids)
+    lo = n - 2_500_000
+    sample, _ = ctx.download_rows(lo, 200_000)
+    for qi in (3, 700):
+        allsc = oracle.scores(sample, po.DT_F16, queries[qi], None)
+        better = np.flatnonzero(allsc > sc[qi, -1]) + lo
+        assert set(better.tolist()) <= set(ids[qi].tolist()), qi
+    del sample
+    ctx.set_option("path", 1)
+    ide, sce = ctx.search_batch(queries, k)                    # 1024 queries x 100M rows on the exact kernel (~8 s)
+    assert ctx.stats()["path"] == 1
+    assert np.array_equal(ide, ids) and np.array_equal(sce.view(np.uint32), sc.view(np.uint32))
+    ctx.close()
+    # (c) what 8 GPUs would each do, one shard at a time on this one, then the device merge of the gathered lists
+    dev = torch.device("cuda", 0)
+    g_ids = torch.empty((shards, nq, k), dtype=torch.int64, device=dev)
+    g_sc = torch.empty((shards, nq, k), dtype=torch.float32, device=dev)
+    t_q = torch.from_numpy(queries).to(dev)
+    stream = torch.cuda.Stream()
+    from nvdb_amd.sharding import shard_range
+    c = nvdb_amd.HipContext(0)
+    for s in range(shards):
+        lo_, hi_ = shard_range(n, s, shards)
+        assert hi_ - lo_ == 12_500_000
+        c.generate_corpus(SEED, hi_ - lo_, d, nvdb_amd.DT_F16, row_base=lo_)
+        with torch.cuda.stream(stream):
+            c.search_batch_dev(t_q.data_ptr(), nq, k, g_ids[s].data_ptr(), g_sc[s].data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        s_st = c.search_check()
+        assert s_st["path"] == 2 and s_st["bound_violations"] == 0 and s_st["overflow_queries"] == 0, (s, s_st)
+    m_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    m_sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    c.merge_topk_dev(g_ids.data_ptr(), g_sc.data_ptr(), shards, nq, k, m_ids.data_ptr(), m_sc.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    c.close()
+    mi, ms = m_ids.cpu().numpy().view(np.uint64), m_sc.cpu().numpy()
+    assert np.array_equal(mi, ids) and np.array_equal(ms.view(np.uint32), sc.view(np.uint32))
+    hi_m, hs_m = nvdb_amd.merge_topk_host(g_ids.cpu().numpy().view(np.uint64), g_sc.cpu().numpy())
+    assert np.array_equal(hi_m, ids) and np.array_equal(hs_m.view(np.uint32), sc.view(np.uint32))
+
+
+def _config5_candidates(rs, n, Q, R, hot_lo):
+    """SURVEY 8(d) config 5 candidate rule without FAISS: random distinct-ish ids, 1 % of the slots 0xFFFFFFFF; here at
+    least half of every list is drawn from rows >= hot_lo (byte offsets beyond 4 GiB)."""
+    cand = rs.randint(0, n, size=(Q, R)).astype(np.uint32)
+    hot = rs.rand(Q, R) < 0.55
+    cand[hot] = rs.randint(hot_lo, n, size=int(hot.sum())).astype(np.uint32)
+    cand[rs.rand(Q, R) < 0.01] = 0xFFFFFFFF                  # skipped slots (nvdb_ivf_eval.cpp:513-516)
+    cand[5, 7] = n + 11                                      # out of range -> skipped (cuda_refine.cu:437)
+    cand[6, :] = 0xFFFFFFFF
+    cand[7, 3:] = 0xFFFFFFFF                                 # fewer valid candidates than K
+    cand[8, 100:140] = n - 1                                 # the very last row, forty times
+    return cand
+
+
+def test_refine_config5_full_size(oracle):
+    """BASELINE configs[4]: exact-L2 refine, fp16 base N = 2.9M x 768 (4.45 GB), Q = 10 000, R = 1024, K = 10.
+    Rows >= 2 796 203 start beyond 4 GiB: their gather needs the 64-bit row offset (kernels_refine.h).  More than half
+    of every candidate list comes from rows >= 2.8M.  Checked against the oracle's restatement of the reference
+    kernel's fp32 order (cuda_refine.cu:326-382, :437; parity unpinned -- DESIGN.md section 6) on the rows copied
+    back from HBM, ids AND distance bits, for 96 queries (first, last and a middle block), for both refine kernels;
+    the two kernels must agree on all 10 000 queries; and against the CPU refine's double accumulation
+    (nvdb_ivf_eval.cpp:232-240, 278-307) within 1e-5 relative."""
+    n, d, Q, R, K = 2_900_000, 768, 10_000, 1024, 10
+    ctx = nvdb_amd.HipContext(0)
+    ctx.generate_corpus(SEED, n, d, nvdb_amd.DT_F16)
+    base, _ = ctx.download_rows(0, n)                          # 4.45 GB to the host: the oracle reads the same bits
+    queries = nvdb_amd.synth_rows_f32(SEED + 2, 0, Q, d)
+    queries[::5] = oracle.f16_to_f32(base[(np.arange(0, Q, 5, dtype=np.int64) * 7919 + 2_800_000) % n])   # self-matches: dist 0
+    queries[8] = oracle.f16_to_f32(base[n - 1:n])[0]
+    rs = np.random.RandomState(55)
+    cand = _config5_candidates(rs, n, Q, R, 2_800_000)
+    cand[::5, 17] = ((np.arange(0, Q, 5, dtype=np.int64) * 7919 + 2_800_000) % n).astype(np.uint32)
+    assert (cand[cand != 0xFFFFFFFF].astype(np.int64) * d * 2 > 2**32).mean() > 0.5
+    sub = np.r_[0:32, 5000:5032, Q - 32:Q]
+    oid, odist = oracle.refine(base, po.DT_F16, queries[sub], cand[sub], K, mode=0)
+    cid, cdist = oracle.refine(base, po.DT_F16, queries[sub], cand[sub], K, mode=1)
+    results = {}
+    for v2 in (1, 0):
+        ctx.set_option("refine_v2", v2)
+        ids, dist, t = ctx.refine_l2_topk(queries, cand, K, want_timing=True)
+        results[v2] = (ids, dist)
+        assert np.array_equal(ids[sub], oid), f"refine_v2={v2}: ids differ from the restated kernel order"
+        assert np.array_equal(dist[sub].view(np.uint32), odist.view(np.uint32)), f"refine_v2={v2}: distance bits differ"
+        valid = ids[sub] != 0xFFFFFFFF
+        assert np.allclose(dist[sub][valid], cdist[valid], rtol=1e-5, atol=1e-7)
+        assert (ids[6] == 0xFFFFFFFF).all() and (dist[6] == np.float32(1e30)).all()
+        assert (ids[7, 3:] == 0xFFFFFFFF).all() and (ids[7, :3] != 0xFFFFFFFF).all()
+        assert (ids[8] == n - 1).all() and (dist[8] == 0.0).all()      # forty copies of the last row, which is query 8 itself
+        assert (dist[::5, 0] == 0.0).all() and np.array_equal(ids[::5, 0], cand[::5, 17])      # the self-matches win
+        assert t.kernel_ms > 0 and t.R == R and t.K == K
+    ctx.set_option("refine_v2", 1)
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1].view(np.uint32), results[1][1].view(np.uint32))
+    ctx.close()
+
+
+def test_refine_f32_rows_beyond_4GiB(oracle):
+    """fp32 base (cuda_refine.cu:383-392, which the reference declares but never launches, :1055-1085): 1.5M x 768 x 4 B =
+    4.6 GB, candidates concentrated in the rows whose byte offset exceeds 4 GiB."""
+    n, d, Q, R, K = 1_500_000, 768, 256, 512, 10
+    ctx = nvdb_amd.HipContext(0)
+    ctx.generate_corpus(SEED + 3, n, d, nvdb_amd.DT_F32)
+    hot_lo = 1_400_000
+    tail, _ = ctx.download_rows(hot_lo, n - hot_lo)
+    queries = nvdb_amd.synth_rows_f32(SEED + 4, 0, Q, d)
+    rs = np.random.RandomState(56)
+    cand = rs.randint(hot_lo, n, size=(Q, R)).astype(np.uint32)
+    cand[rs.rand(Q, R) < 0.01] = 0xFFFFFFFF
+    local = np.where(cand == 0xFFFFFFFF, cand, cand - np.uint32(hot_lo))
+    oid, odist = oracle.refine(tail, po.DT_F32, queries, local, K, mode=0)
+    oid = np.where(oid == 0xFFFFFFFF, oid, oid + np.uint32(hot_lo))
+    for v2 in (1, 0):
+        ctx.set_option("refine_v2", v2)
+        ids, dist = ctx.refine_l2_topk(queries, cand, K)
+        assert np.array_equal(ids, oid) and np.array_equal(dist.view(np.uint32), odist.view(np.uint32)), v2
+    ctx.close()
 
 
 # ----------------------------------------------------------------------------- device-buffer entry points (torch as plumbing)
