@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: flat-scan top-10, d=768, fp16 corpus, batch 1024 (BASELINE.json configs[1]).
+"""bench.py -- flat-scan top-10, d=768, fp16 corpus, batch 1024 (BASELINE.json configs[1] on one GPU, configs[3] on N > 1).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one pass of the hot path over one batch: 1024 fp32 queries (already in HBM) against the
-resident corpus -> exact top-10 (ids + scores) in HBM.  With N GPUs the SAME corpus is row-sharded
-(rows [r*N_rows/N, (r+1)*N_rows/N) on rank r, global ids = shard base + local row), every rank scans
-its shard for the whole batch, the per-shard top-k lists are exchanged with one RCCL all-gather and
-merged on every rank (total work fixed -> "scaling": "strong").
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process NEVER touches the GPU; it starts N ranks of
+itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) and waits for them.
+Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks are already there.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
-the MFMA filter kernel, timed live with HIP events on its stream) and `cpu_baseline` (the real
-reference's AVX2+OpenMP FlatIndexOMP from oracle/_ref on this box's host cores, bounded sample).
+A "step" is one pass of the hot path over one batch: 1024 fp32 queries (already in HBM) against the resident corpus
+-> exact top-10 (ids + scores) in HBM.
+  * N = 1: corpus = 10M rows (configs[1]).
+  * N > 1: corpus = 100M rows (configs[3]), row-sharded: rank r holds rows [r*N_rows/N, (r+1)*N_rows/N) with global ids,
+    every rank scans its shard for the whole batch, ONE RCCL all-gather of the packed per-shard top-k (B*k*12 bytes per
+    rank) and a k-way merge on every rank.  Total work is fixed -> "scaling": "strong"; the 1-GPU point of this series
+    is `extras.fp16_100M_batch1024` of the --gpus 1 line (the whole 100M corpus resident on one GPU).
+
+Rank 0 prints ONE JSON line.  `value` = queries/s with queries and results resident in HBM (contract); the same
+step through the host API (pageable host queries in, results out, self-check read back: PCIe-inclusive) is
+`host_api`.  `roofline`: the dominant kernel timed live by HIP events attached to its launches.  `cpu_baseline`: the
+REAL reference (oracle/_ref: its nvdb_bench binary, AVX2+FMA+F16C, OpenMP) on this box's host cores over the full
+10M-row corpus -- per-query OMP (the north star's "AVX2+OMP CPU path"), single thread, and the batched OMP loop.
 """
 import argparse
-import ctypes
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +40,8 @@ SEED = 20240613
 PEAK_F16_TFLOPS = 2500.0     # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_I8_TOPS = 5000.0        # int8 MFMA = 2x the bf16 rate per clock (same guide, "Matrix cores")
 PEAK_HBM_GBPS = 8000.0       # HBM3E 8 TB/s spec (same guide)
+ROWS_1GPU = 10_000_000       # BASELINE configs[1]
+ROWS_SHARDED = 100_000_000   # BASELINE configs[3]
 
 
 def parse():
@@ -39,89 +49,245 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows (all GPUs together)")
+    ap.add_argument("--rows", type=int, default=0, help="total corpus rows (all GPUs together); default 10M on one GPU, 100M on several")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--dtype", default="f16", choices=["f16", "i8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample-queries", type=int, default=96)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="CPU time the cpu_baseline leg may spend on its timed queries (bounded sample)")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 exact kernel, 2 MFMA filter")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (nvdb_hip_set_option), repeatable")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (HBM-bound point, int8, refine)")
-    ap.add_argument("--verify-merge", action="store_true", help="N>1: rank 0 also searches the unsharded corpus and compares the merged lists")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (HBM-bound point, int8, refine, 100M)")
+    ap.add_argument("--no-verify-merge", action="store_true", help="N>1: skip the merged == unsharded check of the first step")
     ap.add_argument("--sweep", default="", help="comma list of extra batch sizes to time (N=1 only), e.g. 1,16,64,256")
+    ap.add_argument("--dry-launch", action="store_true", help="start the ranks, rendezvous over gloo on the CPU, exchange one tensor, exit (no GPU)")
     return ap.parse_args()
 
 
-def host_cpu_share():
-    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota, by
-    NVDB_CPU_THREADS if set, and by 16 per visible GPU (the GPU box's stated CPU share)."""
+# ------------------------------------------------------------------------------------------ launcher (no GPU touched)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """Parent of a `--gpus N` run started without a launcher: spawn the N ranks as children of a process that has not
+    initialised HIP (no torch.cuda call, libnvdb_hip not loaded) and only waits.  Rank 0 inherits stdout."""
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_WORLD_SIZE=str(n), NVDB_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0:
+                rc = rc or code
+                deadline = deadline or time.time() + 30          # a rank died: give the others a moment, then stop them
+        if deadline and time.time() > deadline:
+            for p in procs:
+                p.kill()
+        time.sleep(0.05)
+    return rc
+
+
+def dry_launch(args, rank, world):
+    """Launcher rehearsal on the CPU: gloo rendezvous + one all-gather of the packed result shape + host merge."""
+    import torch
+    import torch.distributed as dist
+    import nvdb_amd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, K = 4, args.k
+    ids = (torch.arange(B * K, dtype=torch.int64).view(B, K) * world + rank)
+    sc = (-(torch.arange(B * K, dtype=torch.float32).view(B, K) * world + rank))
+    g_ids = torch.empty((world * B, K), dtype=torch.int64)
+    g_sc = torch.empty((world * B, K), dtype=torch.float32)
+    dist.all_gather_into_tensor(g_ids, ids)
+    dist.all_gather_into_tensor(g_sc, sc)
+    mi, ms = nvdb_amd.merge_topk_host(g_ids.view(world, B, K).numpy().view(np.uint64), g_sc.view(world, B, K).numpy())
+    ok = bool((mi[:, 0] == np.arange(B) * K * world).all())
+    dist.barrier()
+    if rank == 0:
+        rows = args.rows or (ROWS_1GPU if world == 1 else ROWS_SHARDED)
+        print(json.dumps({"dry_launch": True, "world": world, "merge_ok": ok, "rows_total": rows,
+                          "rows_per_gpu": rows // world, "launcher": "self" if os.environ.get("NVDB_BENCH_SELF_LAUNCHED") else "external"}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline (reference binaries)
+def host_cpu_info():
+    """threads this process may use (affinity, cgroup quota, NVDB_CPU_THREADS, at most 16 per visible GPU = the box's stated
+    CPU share), plus what the host is."""
     n = len(os.sched_getaffinity(0))
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
             n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
     except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, int(np.ceil(q / p))))
-        except Exception:
-            pass
+        pass
     if os.environ.get("NVDB_CPU_THREADS"):
-        return max(1, int(os.environ["NVDB_CPU_THREADS"]))
-    return min(n, 16)
-
-
-def cpu_baseline(ctx, args, nvdb_amd):
-    """Time the reference's AVX2+OpenMP path (FlatIndexOMP, per query) on a bounded sample."""
-    import pyoracle as po
-    cores = host_cpu_share()
-    n_s, nq_s = min(args.cpu_sample_rows, args.rows), args.cpu_sample_queries
-    rows, rsc = ctx.download_rows(0, n_s)                     # same synthetic rows the GPU scans
-    queries = nvdb_amd.synth_rows_f32(SEED + 1, 0, nq_s, args.dim)
-    scale = n_s / float(args.rows)
-    if po.Reference.available():
-        ref = po.Reference()
-        tmp = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"nvdb_bench_{os.getpid()}.vecbin")
-        try:
-            po.write_vecbin(tmp, rows, po.DT_F16 if args.dtype == "f16" else po.DT_I8, rsc)
-            h = ref.open(tmp)
-            ref.flat_search(h, queries[:4], args.k, mode=1, threads=cores, want_results=False)        # warm-up
-            _, _, ms = ref.flat_search(h, queries, args.k, mode=1, threads=cores, want_results=False)
-            ref.close(h)
-        finally:
-            if os.path.exists(tmp):
-                os.remove(tmp)
-        kind = "reference"
+        n = max(1, int(os.environ["NVDB_CPU_THREADS"]))
     else:
-        orc = po.Oracle()
-        t0 = time.time()
-        for q in queries:
-            orc.flat_topk_omp(rows, po.DT_F16 if args.dtype == "f16" else po.DT_I8, q, args.k, cores, rsc)
-        ms = (time.time() - t0) * 1e3
-        kind = "port"
-    qps_sample = nq_s / (ms * 1e-3)
-    return {"value": qps_sample * scale, "unit": "queries/s", "cores": cores, "kind": kind,
-            "sample": f"{nq_s} queries, one at a time (FlatIndexOMP, {cores} OpenMP threads) over the first {n_s} rows of the same "
-                      f"{args.dtype} corpus: {qps_sample:.2f} queries/s measured ({n_s * args.dim * (2 if args.dtype == 'f16' else 1) * qps_sample / 1e9:.1f} GB/s), "
-                      f"scaled by {n_s}/{args.rows} rows"}
+        n = min(n, 16)
+    model, sockets, phys = "unknown", 1, None
+    try:
+        txt = open("/proc/cpuinfo").read()
+        m = re.search(r"model name\s*:\s*(.+)", txt)
+        model = m.group(1).strip() if m else model
+        sockets = max(1, len(set(re.findall(r"physical id\s*:\s*(\d+)", txt))))
+        phys = len(set(re.findall(r"physical id\s*:\s*(\d+)\n(?:.*\n)*?core id\s*:\s*(\d+)", txt))) or None
+    except Exception:
+        pass
+    return {"threads_used": n, "cpu_model": model, "sockets": sockets, "physical_cores_visible": phys, "logical_cpus_visible": os.cpu_count()}
 
 
+def scratch_dir(need_bytes):
+    """/dev/shm when it has the room (the file then sits in RAM like the reference's warm page cache), else $TMPDIR or /tmp."""
+    for d in ("/dev/shm", os.environ.get("TMPDIR", ""), "/tmp"):
+        try:
+            if d and os.path.isdir(d):
+                v = os.statvfs(d)
+                if v.f_bavail * v.f_frsize > need_bytes * 1.05:
+                    return d
+        except OSError:
+            pass
+    return "/tmp"
+
+
+def _ref_bench(ref_bin, base, qfile, k, mode, threads, warmup, batch_q=1, tile=512, timeout=600):
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+    cmd = [os.path.join(ref_bin, "nvdb_bench"), base, qfile, str(k), mode, str(threads), str(warmup)]
+    if batch_q > 1:
+        cmd += [str(batch_q), str(tile), "0"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, check=True).stdout
+    m = re.search(r"Avg_query:\s*([\d.]+) ms/query\s*\(([\d.]+) QPS\)", out)
+    sink = re.search(r"sink=(\S+)", out)
+    return float(m.group(1)), float(m.group(2)), sink.group(1) if sink else None
+
+
+def cpu_baseline(ctx, args, nvdb_amd, N):
+    """The reference's CPU path on the FULL corpus of this run (no extrapolation): rows copied back from HBM into a
+    vecbin in /dev/shm, then the reference's own nvdb_bench binary (oracle/_ref/bin, built from /root/reference by
+    oracle/Makefile) -- per-query OpenMP = FlatIndexOMP (the headline `value`), single thread = FlatIndex, and the
+    bench-side batched OpenMP loop (apps/nvdb_bench.cpp:47-159, batch_q=8 tile_vecs=512, the published setting).
+    Query counts are sized from a first timed query so that the leg stays within --cpu-seconds."""
+    import pyoracle as po
+    info = host_cpu_info()
+    T = info["threads_used"]
+    D, K = args.dim, args.k
+    dt_o = po.DT_F16 if args.dtype == "f16" else po.DT_I8
+    bpr = D * 2 if args.dtype == "f16" else D + 4
+    shm = scratch_dir(N * bpr + (64 << 20))
+    base_p = os.path.join(shm, f"nvdb_bench_{os.getpid()}.vecbin")
+    q_p = os.path.join(shm, f"nvdb_bench_{os.getpid()}_q.raw12")
+    res = {"unit": "queries/s", "cores": T, "host": info}
+    try:
+        # corpus file: header + payload streamed from HBM in slabs (+ scales for int8); 15.36 GB for the headline config
+        import struct
+        slab = 500_000
+        with open(base_p, "wb") as f:
+            f.write(struct.pack("<QIIIIQ", po.VEC_MAGIC, 1, dt_o, D, 0, N) + b"\0" * 32)
+            scales = []
+            for r0 in range(0, N, slab):
+                rows, sc = ctx.download_rows(r0, min(slab, N - r0))
+                f.write(rows.tobytes())
+                if sc is not None:
+                    scales.append(sc)
+            if scales:
+                f.write(np.concatenate(scales).astype(np.float32).tobytes())
+        queries = nvdb_amd.synth_rows_f32(SEED + 1, 0, 256, D)
+        if not po.Reference.available():
+            raise RuntimeError("oracle/_ref is missing (built only where /root/reference exists)")
+        ref_bin = po.Reference().bin
+        budget = args.cpu_seconds
+
+        def timed(mode, threads, batch_q, share):
+            # probe with one query (plus the reference's own warm-up query), then size the run
+            po.write_raw12(q_p, queries[:max(1, batch_q)])
+            ms1, _, _ = _ref_bench(ref_bin, base_p, q_p, K, mode, threads, 1, batch_q)
+            nq = int(max(batch_q, min(256, (budget * share * 1e3) / max(ms1, 1e-3))))
+            nq = max(batch_q, nq // batch_q * batch_q)
+            po.write_raw12(q_p, queries[:nq])
+            ms, qps, sink = _ref_bench(ref_bin, base_p, q_p, K, mode, threads, 1, batch_q)
+            return {"qps": qps, "ms_per_query": ms, "queries": nq, "threads": threads, "GBps": N * bpr * qps / 1e9, "sink": sink}
+        omp = timed("omp", T, 1, 0.45)
+        st = timed("st", 1, 1, 0.2)
+        bat = timed("omp", T, 8, 0.35)
+        res.update({"value": omp["qps"], "kind": "reference",
+                    "sample": f"{omp['queries']} queries one at a time, FlatIndexOMP with {T} OpenMP threads (OMP_PROC_BIND=close OMP_PLACES=cores), "
+                              f"over ALL {N} rows of the same {args.dtype} corpus (d={D}, k={K}); reference binary oracle/_ref/bin/nvdb_bench",
+                    "per_query_omp": omp, "single_thread": st, "batched_omp_batch8_tile512": bat})
+    finally:
+        for p in (base_p, q_p):
+            if os.path.exists(p):
+                os.remove(p)
+    return res
+
+
+def config0_plumbing(nvdb_amd, args):
+    """BASELINE configs[0]: fp32 flat scan, N=500K d=768, single-thread CPU via nvdb_bench (no GPU in the measured path).
+    The product's host tool (nano-vectordb_amd/bin/nvdb_bench, mode st) and the reference's binary run on the same
+    vecbin; their `sink` (sum of top-1 scores) must agree.  Corpus rows come from the device generator."""
+    import pyoracle as po
+    n, D, K, nq = 500_000, args.dim, args.k, 16
+    shm = scratch_dir(n * D * 4 + (64 << 20))
+    base_p, q_p = os.path.join(shm, f"nvdb_cfg0_{os.getpid()}.vecbin"), os.path.join(shm, f"nvdb_cfg0_{os.getpid()}_q.raw12")
+    out = {"workload": f"fp32 flat-scan top-{K}, N={n} d={D}, single thread, nvdb_bench st"}
+    try:
+        c = nvdb_amd.HipContext(0)
+        c.generate_corpus(SEED, n, D, nvdb_amd.DT_F32)
+        rows, _ = c.download_rows(0, n)
+        c.close()
+        po.write_vecbin(base_p, rows, po.DT_F32)
+        del rows
+        po.write_raw12(q_p, nvdb_amd.synth_rows_f32(SEED + 1, 0, nq, D))
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        ours = subprocess.run([os.path.join(ROOT, "nano-vectordb_amd", "bin", "nvdb_bench"), base_p, q_p, str(K), "st", "1", "1"],
+                              env=env, capture_output=True, text=True, timeout=300, check=True).stdout
+        m = re.search(r"Avg_query:\s*([\d.]+) ms/query\s*\(([\d.]+) QPS\)", ours)
+        out["host_tool"] = {"ms_per_query": float(m.group(1)), "qps": float(m.group(2)), "sink": re.search(r"sink=(\S+)", ours).group(1)}
+        if po.Reference.available():
+            ms, qps, sink = _ref_bench(po.Reference().bin, base_p, q_p, K, "st", 1, 1)
+            out["reference"] = {"ms_per_query": ms, "qps": qps, "sink": sink}
+            out["sink_equal"] = sink == out["host_tool"]["sink"]
+    finally:
+        for p in (base_p, q_p):
+            if os.path.exists(p):
+                os.remove(p)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ the benchmark
 def main():
     args = parse()
-    import torch
-    import nvdb_amd
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))          # nothing above this line has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dry_launch:
+        sys.exit(dry_launch(args, rank, world))
+
+    import torch
+    import nvdb_amd
+
     # NVDB_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank uses device 0 and the exchange goes through
     # gloo on host copies -- same sharding / all-gather / merge logic, no RCCL (RCCL refuses two ranks on one device).
     share_gpu = os.environ.get("NVDB_BENCH_SHARE_GPU", "0") == "1"
@@ -135,7 +301,6 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -143,7 +308,8 @@ def main():
 
     dt = nvdb_amd.DT_F16 if args.dtype == "f16" else nvdb_amd.DT_I8
     bpr = args.dim * 2 if args.dtype == "f16" else args.dim + 4      # algorithmic bytes per corpus row
-    N, B, D, K = args.rows, args.batch, args.dim, args.k
+    N = args.rows or (ROWS_1GPU if world == 1 else ROWS_SHARDED)
+    B, D, K = args.batch, args.dim, args.k
     from nvdb_amd.sharding import shard_range
     lo, hi = shard_range(N, rank, world)
     ctx = nvdb_amd.HipContext(local_rank)
@@ -167,10 +333,11 @@ def main():
         m_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
         m_sc = torch.empty((B, K), dtype=torch.float32, device=dev)
 
-    def step(i, batch=B):
+    def step(i, batch=B, c=None):
+        c = c or ctx
         stream = torch.cuda.current_stream().cuda_stream
         q = qdev[(i % nbatches) * B:(i % nbatches) * B + batch]
-        ctx.search_batch_dev(q.data_ptr(), batch, K, out_ids.data_ptr(), out_sc.data_ptr(), stream)
+        c.search_batch_dev(q.data_ptr(), batch, K, out_ids.data_ptr(), out_sc.data_ptr(), stream)
         if world > 1:
             if share_gpu:
                 cg = torch.empty(world * PACK, dtype=torch.uint8)
@@ -178,8 +345,8 @@ def main():
                 gathered.copy_(cg)
             else:
                 dist.all_gather_into_tensor(gathered, packed)   # RCCL over xGMI: B*k*(8+4) = 123 KB per rank, one collective
-            ctx.merge_topk_strided_dev(gathered.data_ptr(), gathered.data_ptr() + B * K * 8, PACK, PACK, world, batch, K,
-                                       m_ids.data_ptr(), m_sc.data_ptr(), stream)
+            c.merge_topk_strided_dev(gathered.data_ptr(), gathered.data_ptr() + B * K * 8, PACK, PACK, world, batch, K,
+                                     m_ids.data_ptr(), m_sc.data_ptr(), stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -187,72 +354,75 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_steps(nsteps, first=0, batch=B, c=None):
+        """barrier + sync, nsteps steps, barrier + sync; MAX over ranks.  The self-check of EVERY step is read afterwards
+        (sticky flags of nvdb_hip_search_check; raises on overflow / bound violation)."""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            step(first + i, batch, c)
+        barrier()
+        el = time.perf_counter() - t0
+        st = (c or ctx).search_check()
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, st
+
     # ---- untimed: warm-up + parity self-check ---------------------------------------------------------
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    st = ctx.search_check()                                    # raises on overflow / bound violation
+    ctx.search_check()                                         # raises on overflow / bound violation in any warm-up step
     parity = "skipped"
     if rank == 0:
         # Self-check without the oracle (the oracle only serves the cpu_baseline leg here; tests/ pin the exact
-        # fp32 kernel against it): the MFMA filter path must reproduce the exact fp32-order kernel bit for bit.
-        # Local search only -- no collective in this branch, the other ranks are not in it.
-        ctx.search_batch_dev(qdev[:B].data_ptr(), B, K, out_ids.data_ptr(), out_sc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        # fp32 kernel against it, and compare ALL queries at 10M and 100M rows): the MFMA filter path must reproduce
+        # the exact fp32-order kernel bit for bit.  Local search only -- no collective in this branch.
+        npar = 64 if world == 1 else 8
+        strm = torch.cuda.current_stream().cuda_stream
+        ctx.search_batch_dev(qdev[:B].data_ptr(), B, K, out_ids.data_ptr(), out_sc.data_ptr(), strm)
         torch.cuda.synchronize()
-        fi, fs = out_ids[:8].cpu().numpy().astype(np.uint64), out_sc[:8].cpu().numpy()
+        fi, fs = out_ids[:npar].cpu().numpy().astype(np.uint64), out_sc[:npar].cpu().numpy()
         ctx.set_option("path", 1)
-        ctx.search_batch_dev(qdev[:8].data_ptr(), 8, K, out_ids.data_ptr(), out_sc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        ctx.search_batch_dev(qdev[:npar].data_ptr(), npar, K, out_ids.data_ptr(), out_sc.data_ptr(), strm)
         torch.cuda.synchronize()
-        ei, es = out_ids[:8].cpu().numpy().astype(np.uint64), out_sc[:8].cpu().numpy()
+        ei, es = out_ids[:npar].cpu().numpy().astype(np.uint64), out_sc[:npar].cpu().numpy()
         ctx.set_option("path", args.path)
+        ctx.search_check()
         ok = np.array_equal(fi, ei) and np.array_equal(fs.view(np.uint32), es.view(np.uint32))
-        parity = "ok: MFMA path == exact fp32-order kernel (ids and score bits, 8 queries)" if ok else "FAILED"
+        parity = f"ok: MFMA path == exact fp32-order kernel (ids and score bits, {npar} queries)" if ok else "FAILED"
         if not ok:
             raise SystemExit("parity self-check failed: filter path != exact path")
     barrier()
 
+    # ---- N > 1: the merged lists of one step against the unsharded corpus on rank 0 -------------------------
     merge_check = None
-    if world > 1 and args.verify_merge:
+    if world > 1 and not args.no_verify_merge:
         step(0)
         torch.cuda.synchronize()
-        if os.environ.get("NVDB_BENCH_DEBUG") == "1":
-            di, ds = out_ids.cpu().numpy().astype(np.uint64), out_sc.cpu().numpy()
-            hi_, hs_ = ctx.search_batch(qhost[:B], K)
-            gi = gathered.cpu().numpy()
-            g_ids = [gi[w * PACK:w * PACK + B * K * 8].view(np.uint64).reshape(B, K) for w in range(world)]
-            print(f"[debug rank {rank}] gathered part {rank} == my packed: {bool((g_ids[rank] == di).all())}; gathered q0 parts: "
-                  f"{[g[0, :3].tolist() for g in g_ids]}; merged q0 {m_ids[0, :4].tolist()}", flush=True)
-            print(f"[debug rank {rank}] device-path vs host-path on my shard: {int((di != hi_).sum())} id mismatches; "
-                  f"q0 dev {di[0, :3].tolist()} {ds[0, :3].tolist()} host {hi_[0, :3].tolist()} {hs_[0, :3].tolist()}", flush=True)
-            barrier()
         if rank == 0:
-            full = nvdb_amd.HipContext(local_rank)
-            full.generate_corpus(SEED, N, D, dt, row_base=0)
-            fi, fs = full.search_batch(qhost[:B], K)
-            full.close()
-            mi, ms_ = m_ids.cpu().numpy().astype(np.uint64), m_sc.cpu().numpy()
-            merge_check = bool(np.array_equal(mi, fi) and np.array_equal(ms_.view(np.uint32), fs.view(np.uint32)))
-            if not merge_check:
-                bad = np.argwhere(mi != fi)
-                detail = "; ".join(f"q{a} #{j}: full ({fi[a, j]}, {fs[a, j]:.6f}) merged ({mi[a, j]}, {ms_[a, j]:.6f})" for a, j in bad[:6])
-                raise SystemExit(f"sharded + merged result differs from the unsharded search: {len(bad)} of {mi.size} ids; {detail}")
+            try:
+                full = nvdb_amd.HipContext(local_rank)
+                full.generate_corpus(SEED, N, D, dt, row_base=0)       # 153.6 GB at N=100M: fits beside the rank's shard
+                fi, fs = full.search_batch(qhost[:B], K)
+                full.close()
+                mi, ms_ = m_ids.cpu().numpy().astype(np.uint64), m_sc.cpu().numpy()
+                merge_check = bool(np.array_equal(mi, fi) and np.array_equal(ms_.view(np.uint32), fs.view(np.uint32)))
+                if not merge_check:
+                    bad = np.argwhere(mi != fi)
+                    detail = "; ".join(f"q{a} #{j}: full ({fi[a, j]}, {fs[a, j]:.6f}) merged ({mi[a, j]}, {ms_[a, j]:.6f})" for a, j in bad[:6])
+                    raise SystemExit(f"sharded + merged result differs from the unsharded search: {len(bad)} of {mi.size} ids; {detail}")
+            except nvdb_amd.NvdbError as e:
+                merge_check = f"skipped: {e}"
         barrier()
 
     # ---- timed region ---------------------------------------------------------------------------------
     ctx.set_option("time_kernels", 0 if os.environ.get("NVDB_BENCH_NO_KERNEL_EVENTS") == "1" else 1)   # diagnosis only: roofline becomes null
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, stats = timed_steps(args.steps, first=args.warmup)
     ctx.set_option("time_kernels", 0)
     kt = ctx.collect_kernel_times()
-    stats = ctx.search_check()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
 
     qps = args.steps * B / elapsed
     ms_per_step = elapsed * 1e3 / args.steps
@@ -261,11 +431,14 @@ def main():
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f16" if args.dtype == "f16" else "i8", "data": "synthetic",
-        "config": {"workload": f"{'fp16' if args.dtype == 'f16' else 'int8+scale'} flat-scan top-{K}, N={N} d={D}, batch={B}", "rows_total": N,
-                   "rows_per_gpu": hi - lo, "batch": B, "k": K, "dim": D,
-                   "parallelism": "1 GPU" if world == 1 else f"corpus row-sharded x{world}, RCCL all-gather of per-shard top-k"},
+        "config": {"workload": f"{'fp16' if args.dtype == 'f16' else 'int8+scale'} flat-scan top-{K}, N={N} d={D}, batch={B}"
+                               + (" (BASELINE configs[1])" if (N, world) == (ROWS_1GPU, 1) else " (BASELINE configs[3])" if N == ROWS_SHARDED else ""),
+                   "rows_total": N, "rows_per_gpu": hi - lo, "batch": B, "k": K, "dim": D,
+                   "parallelism": "1 GPU" if world == 1 else f"corpus row-sharded x{world}, RCCL all-gather of per-shard top-k",
+                   "series": None if world == 1 else "strong scaling over the 100M-row corpus; its 1-GPU point is extras.fp16_100M_batch1024 of the --gpus 1 line"},
         "effective_hbm_GBps": (N * bpr / 1e9) / (ms_per_step * 1e-3),          # corpus bytes / pass time, all GPUs
         "parity": parity, "merge_check": merge_check,
+        "self_check": "every timed step checked (sticky flags): no list overflow, no bound violation",
         "scan": {"path": stats["path"], "chunks": stats["chunks"], "candidates_per_query": stats["candidates"] / max(B, 1),
                  "bound_violations": stats["bound_violations"], "overflow_queries": stats["overflow_queries"]},
     }
@@ -277,17 +450,19 @@ def main():
         gbps = kt["bytes"] / sec / 1e9
         # ridge point: intensity = 2*B*dim flop per row / row bytes  vs  peak flop / peak bytes
         hbm_bound = (2.0 * B * D / bpr) < (peak * 1e12 / (PEAK_HBM_GBPS * 1e9))
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             ent = tj.get(f"{'fp16' if args.dtype == 'f16' else 'int8'} N={N} d={D} batch={B}")
             if ent and world == 1:
-                traffic = ent["bytes_per_launch"]       # measured in a separate --pmc pass of this same command line
+                traffic = ent["bytes_per_launch"]
+                traffic_source = ("profiles/traffic.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE of a separate rocprofv3 --pmc pass of this "
+                                  f"command ({ent.get('source', 'see profiles/README.md')}); not measured in this run")
         except Exception:
             pass
-        common = {"traffic": traffic, "kernel": kname, "launches": kt["launches"], "avg_launch_ms": kt["ms"] / kt["launches"],
-                  "kernel_time_share": kt["ms"] / (elapsed * 1e3), "mfma_T_per_s": ach, "mfma_frac": ach / peak,
-                  "hbm_GBps_algorithmic": gbps, "hbm_frac": gbps / PEAK_HBM_GBPS}
+        common = {"traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "launches": kt["launches"],
+                  "avg_launch_ms": kt["ms"] / kt["launches"], "kernel_time_share": kt["ms"] / (elapsed * 1e3), "mfma_T_per_s": ach,
+                  "mfma_frac": ach / peak, "hbm_GBps_algorithmic": gbps, "hbm_frac": gbps / PEAK_HBM_GBPS}
         if hbm_bound:
             out["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, **common}
         else:
@@ -297,6 +472,27 @@ def main():
     else:
         out["roofline"] = None
 
+    # ---- the same step through the host API of the C ABI (PCIe-inclusive; never `value`) --------------------------
+    if world == 1:
+        reps = max(2, min(args.steps, 8))
+        ctx.search_batch(qhost[:B], K)
+        t0 = time.perf_counter()
+        for i in range(reps):
+            ctx.search_batch(qhost[(i % nbatches) * B:(i % nbatches + 1) * B], K)
+        el = (time.perf_counter() - t0) / reps
+        out["host_api"] = {"call": "nvdb_hip_search_batch: pageable host queries in (3.1 MB H2D), ids + scores out (123 KB D2H), self-check read back, one synchronisation per call",
+                           "qps": B / el, "ms_per_step": el * 1e3, "overhead_vs_device_resident_ms": el * 1e3 - ms_per_step}
+
+    # ---- N > 1: the 10M-row corpus of configs[1] sharded the same way (small shards: fixed costs weigh more) -----------
+    if world > 1 and not args.no_extras:
+        lo2, hi2 = shard_range(ROWS_1GPU, rank, world)
+        ctx.generate_corpus(SEED, hi2 - lo2, D, dt, row_base=lo2)
+        for i in range(2):
+            step(i)
+        el2, _ = timed_steps(args.steps)
+        out["extras"] = {"strong_10M": {"workload": f"fp16 flat-scan top-{K}, N={ROWS_1GPU} d={D}, batch={B}, row-sharded x{world}",
+                                        "rows_per_gpu": hi2 - lo2, "qps": args.steps * B / el2, "ms_per_step": el2 * 1e3 / args.steps}}
+
     # ---- optional batch sweep (HBM-bound points), N=1 only ---------------------------------------------
     if args.sweep and world == 1:
         sweep = []
@@ -305,16 +501,10 @@ def main():
             for i in range(2):
                 step(i, b)
             ctx.set_option("time_kernels", 1)
-            barrier()
-            t0 = time.perf_counter()
             reps = max(2, min(args.steps, 8))
-            for i in range(reps):
-                step(i, b)
-            barrier()
-            el = time.perf_counter() - t0
+            el, s2 = timed_steps(reps, batch=b)
             ctx.set_option("time_kernels", 0)
             k2 = ctx.collect_kernel_times()
-            s2 = ctx.search_check()
             sweep.append({"batch": b, "qps": reps * b / el, "ms_per_pass": el * 1e3 / reps, "path": s2["path"],
                           "hbm_GBps": N * bpr / 1e9 / (el / reps), "hbm_frac": N * bpr / 1e9 / (el / reps) / PEAK_HBM_GBPS,
                           "tflops": 2.0 * b * N * D / (el / reps) / 1e12,
@@ -325,35 +515,28 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras and args.dtype == "f16":
         extras = {}
         try:
-            def timed_passes(c, qd, b, reps=6):
-                oi = torch.empty((b, K), dtype=torch.int64, device=dev)
-                os_ = torch.empty((b, K), dtype=torch.float32, device=dev)
-                strm = torch.cuda.current_stream().cuda_stream
-                for _ in range(2):
-                    c.search_batch_dev(qd.data_ptr(), b, K, oi.data_ptr(), os_.data_ptr(), strm)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    c.search_batch_dev(qd.data_ptr(), b, K, oi.data_ptr(), os_.data_ptr(), strm)
-                torch.cuda.synchronize()
-                el = (time.perf_counter() - t0) / reps
-                timed_passes.last_stats = c.search_check()
-                return el
+            def timed_passes(c, b, reps=6):
+                for i in range(2):
+                    step(i, b, c)
+                el, st_ = timed_steps(reps, batch=b, c=c)
+                timed_passes.last_stats = st_
+                return el / reps
             # (1) HBM-bound point of the same fp16 corpus: batch 64
-            el = timed_passes(ctx, qdev, 64)
+            el = timed_passes(ctx, 64)
             extras["fp16_batch64"] = {"workload": f"fp16 flat-scan top-{K}, N={N} d={D}, batch=64", "qps": 64 / el, "ms_per_pass": el * 1e3,
                                       "hbm_GBps": N * D * 2 / 1e9 / el, "hbm_frac": N * D * 2 / 1e9 / el / PEAK_HBM_GBPS}
             # (2) BASELINE configs[2]: int8(+scale), same shape
             c8 = nvdb_amd.HipContext(local_rank)
             c8.generate_corpus(SEED, N, D, nvdb_amd.DT_I8)
             for bb in (B, 64):
-                el = timed_passes(c8, qdev, bb)
+                el = timed_passes(c8, bb)
                 extras[f"int8_batch{bb}"] = {"workload": f"int8+scale flat-scan top-{K}, N={N} d={D}, batch={bb}", "qps": bb / el, "ms_per_pass": el * 1e3,
                                              "hbm_GBps": N * (D + 4) / 1e9 / el, "hbm_frac": N * (D + 4) / 1e9 / el / PEAK_HBM_GBPS,
                                              "algorithmic_TOPs": 2.0 * bb * N * D / el / 1e12,
                                              "two_stage": {"tiles_past_quick_test": timed_passes.last_stats.get("i8_stage1_tiles"),
                                                            "lo_plane_blocks": timed_passes.last_stats.get("i8_stage2_blocks"),
                                                            "wave_tiles": (N // 64) * ((bb + 63) // 64 if bb > 128 else (bb + 31) // 32)}}
+            c8.close()
             # recall@10 of the int8 corpus against the fp32 corpus' exact top-10 (500K-row prefix, 64 queries)
             nr = min(N, 500_000)
             c32 = nvdb_amd.HipContext(local_rank)
@@ -365,7 +548,6 @@ def main():
             i_ids, _ = c8s.search_batch(qhost[:64], K)
             c8s.close()
             extras["int8_recall_at_10_vs_fp32"] = float(np.mean([len(set(a.tolist()) & set(b_.tolist())) / K for a, b_ in zip(g_ids, i_ids)]))
-            c8.close()
             # (3) BASELINE configs[4]: exact-L2 refine, N=2.9M fp16, Q=10000, R=1024, K=10, synthetic candidates
             NR, QR, RR = min(N, 2_900_000), 10_000, 1024
             cr = nvdb_amd.HipContext(local_rank)
@@ -379,19 +561,37 @@ def main():
                 _, _, t = cr.refine_l2_topk(rq, cand, K, want_timing=True)
                 best = t.kernel_ms if best is None else min(best, t.kernel_ms)
             cr.close()
-            gb = QR * RR * 0.99 * D * 2 / 1e9
-            extras["refine"] = {"workload": f"exact-L2 refine N={NR} Q={QR} R={RR} K={K} fp16", "kernel_ms": best, "us_per_query": best * 1e3 / QR,
-                                "h2d_ms": t.h2d_ms, "d2h_ms": t.d2h_ms, "gather_GBps": gb / (best * 1e-3), "hbm_frac": gb / (best * 1e-3) / PEAK_HBM_GBPS}
+            gb = float((cand != 0xFFFFFFFF).sum()) * D * 2 / 1e9
+            extras["refine"] = {"workload": f"exact-L2 refine N={NR} Q={QR} R={RR} K={K} fp16", "kernel": "refine_l2_rows_kernel<768>",
+                                "kernel_ms": best, "us_per_query": best * 1e3 / QR, "h2d_ms": t.h2d_ms, "d2h_ms": t.d2h_ms,
+                                "gather_GBps": gb / (best * 1e-3), "hbm_frac": gb / (best * 1e-3) / PEAK_HBM_GBPS}
+            del cand, rq
+            # (4) the north star's target point: N=100M (153.6 GB resident on this one GPU), batch 64 (HBM-bound) and 1024
+            c100 = nvdb_amd.HipContext(local_rank)
+            c100.generate_corpus(SEED, ROWS_SHARDED, D, nvdb_amd.DT_F16)
+            for bb, reps in ((64, 4), (B, 3)):
+                el = timed_passes(c100, bb, reps)
+                extras[f"fp16_100M_batch{bb}"] = {"workload": f"fp16 flat-scan top-{K}, N={ROWS_SHARDED} d={D}, batch={bb}, one GPU", "qps": bb / el,
+                                                  "ms_per_pass": el * 1e3, "hbm_GBps": ROWS_SHARDED * D * 2 / 1e9 / el,
+                                                  "hbm_frac": ROWS_SHARDED * D * 2 / 1e9 / el / PEAK_HBM_GBPS,
+                                                  "mfma_TFLOPs": 2.0 * bb * ROWS_SHARDED * D / el / 1e12,
+                                                  "mfma_frac": 2.0 * bb * ROWS_SHARDED * D / el / 1e12 / PEAK_F16_TFLOPS}
+            c100.close()
         except Exception as e:
             extras["error"] = repr(e)
         out["extras"] = extras
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(ctx, args, nvdb_amd)
+            out["cpu_baseline"] = cpu_baseline(ctx, args, nvdb_amd, N)
         except Exception as e:                                   # never let the baseline leg kill the bench line
-            out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": host_cpu_share(), "kind": "error",
+            out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": host_cpu_info()["threads_used"], "kind": "error",
                                    "sample": repr(e)}
+        ctx.close()
+        try:
+            out["cpu_baseline"]["config0_fp32_500K_st"] = config0_plumbing(nvdb_amd, args)
+        except Exception as e:
+            out["cpu_baseline"]["config0_fp32_500K_st"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()

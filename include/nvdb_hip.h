@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NVDB_HIP_ABI_VERSION 1
+#define NVDB_HIP_ABI_VERSION 2
 
 /* dtype codes == VecbinHeader::dtype (include/nvdb/vecbin_format.h:10-14) */
 enum { NVDB_DTYPE_F32 = 1, NVDB_DTYPE_F16 = 2, NVDB_DTYPE_I8 = 3 };
@@ -38,9 +38,9 @@ typedef enum nvdb_status {
   NVDB_ERR_INTERNAL = 5      /* a self-check failed (filter error bound violated, overflow ...)   */
 } nvdb_status;
 
-/* Largest k the GPU flat path selects (reference: unbounded, src/flat_index.cpp:24) and largest K
- * of the refine path (reference: NVDB_CUDA_KMAX = 64, src/cuda_refine.cu:12-14, 858-862). */
-#define NVDB_HIP_FLAT_KMAX 64
+/* The flat path takes ANY k (clamped to the row count like the reference, src/flat_index.cpp:24): k <= 64 runs on
+ * wavefront-resident lists / the MFMA filter, larger k on the any-k path (scores -> radix select -> sort).
+ * Largest K of the refine path = the reference's NVDB_CUDA_KMAX = 64 (src/cuda_refine.cu:12-14, 858-862). */
 #define NVDB_HIP_REFINE_KMAX 64
 
 typedef struct nvdb_hip_ctx nvdb_hip_ctx;
@@ -62,7 +62,7 @@ typedef struct nvdb_hip_timing {
 
 /* What the last flat search did (for tests, bench.py and the roofline arithmetic). */
 typedef struct nvdb_hip_scan_stats {
-  uint32_t path;               /* 1 = exact fp32 scan, 2 = MFMA filter + exact rescore            */
+  uint32_t path;               /* 1 = exact fp32 scan, 2 = MFMA filter + exact rescore, 3 = any-k (k > 64) */
   uint32_t chunks;             /* corpus chunks (kernel launches of the dominant kernel)          */
   uint64_t rows_scanned;       /* rows x query-tiles streamed by the dominant kernel              */
   uint64_t candidates;         /* (query,row) pairs that reached the exact rescore                */
@@ -72,6 +72,8 @@ typedef struct nvdb_hip_scan_stats {
   float    other_kernel_ms;    /* prep + select + rescore + merge                                  */
   uint32_t i8_stage1_tiles;    /* int8 two-stage kernel: (wave, tile) pairs that went past the hi-plane quick test */
   uint32_t i8_stage2_blocks;   /* ... 32-query blocks for which the lo plane was multiplied after all           */
+  uint32_t sticky_overflow;    /* nvdb_hip_search_check: a list / log overflow in ANY device-API search since the last check */
+  uint32_t sticky_violations;  /* ... bound violations summed over those searches (both cleared by the check)    */
 } nvdb_hip_scan_stats;
 
 /* ---------------------------------------------------------------------------------------------
@@ -130,7 +132,7 @@ nvdb_status nvdb_hip_download_rows(nvdb_hip_ctx* ctx, uint64_t row0, uint64_t nr
  *   (optional) receives min(k, n); slots >= k_eff hold id UINT64_MAX / score -inf.
  *   Scores are bit-identical to the reference's AVX2 kernels (simd_dot.cpp:26-49, 102-124,
  *   160-199); ties are ordered (score desc, id asc).
- *   k == 0 -> NVDB_OK, nothing written (flat_index.cpp:18).  k > NVDB_HIP_FLAT_KMAX -> INVALID. */
+ *   k == 0 -> NVDB_OK, nothing written (flat_index.cpp:18).  Any k > 0 is accepted. */
 nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* ctx, const float* queries, uint32_t nq, uint32_t k,
                                   uint64_t* out_ids, float* out_scores, uint32_t* out_k_eff,
                                   nvdb_hip_timing* timing);
@@ -140,7 +142,8 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* ctx, const float* queries, uint3
  * handle NULL: a caller whose other work is on the default stream must pass an explicit stream or synchronise the
  * device, the context's stream is not ordered with it).  Returns after enqueueing; no host sync, so
  * overflow / bound self-checks are reported by nvdb_hip_search_check() after the caller has
- * synchronised the stream.  This is the form the multi-GPU path uses before its all-gather. */
+ * synchronised the stream; the check covers EVERY search enqueued since the previous check (sticky flags), its
+ * per-query detail and statistics describe the last one.  This is the form the multi-GPU path uses before its all-gather. */
 nvdb_status nvdb_hip_search_batch_dev(nvdb_hip_ctx* ctx, const float* dev_queries, uint32_t nq, uint32_t k,
                                       uint64_t* dev_out_ids, float* dev_out_scores, void* hip_stream);
 nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* ctx, nvdb_hip_scan_stats* stats);
@@ -165,7 +168,7 @@ nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint3
 /* Tunables (defaults are what bench.py measures; the table with meanings is in INTEGRATION.md section 4b):
  * "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "chunk_growth", "cand_cap", "min_filter_batch", "mfma_boot",
  * "mfma16", "waves8", "sibling_sync", "sync_every", "sync_lead", "tile_permute", "f32_shadow" (set before the upload),
- * "i8_wide", "rescore8", "refine_v2", "time_kernels" (1: start / stop events attached to every launch of the dominant
+ * "i8_wide", "rescore8", "refine_v2", "largek_budget_mb" (HBM for the any-k path's score matrix), "time_kernels" (1: start / stop events attached to every launch of the dominant
  * kernel).  Unknown key -> NVDB_ERR_INVALID. */
 nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* ctx, const char* key, int64_t value);
 

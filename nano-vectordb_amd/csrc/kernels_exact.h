@@ -310,8 +310,19 @@ __global__ __launch_bounds__(256) void select_kernel(
   const uint32_t q = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
   uint32_t m = (mode == 2) ? out_k : cnt[q];     // mode 2 (bootstrap): every list holds exactly out_k tile maxima
   if (m > cap) { if (tid == 0) overflow[q] = 1u; m = cap; }
-  // final select: fold the per-query flags (list overflow, non-finite query) into one word the host can read alone
-  if (mode == 1 && tid == 0 && overflow[q]) atomicOr(any_overflow, 1u);
+  // final select: fold the per-query flags (list overflow, non-finite query) into one word the host can read alone,
+  // and everything this search's self-checks found into the STICKY words any_overflow[6..8] (= misc[12..14]), which
+  // survive later searches until nvdb_hip_search_check reads and clears them -- a caller that enqueues many searches
+  // and checks once still learns about a failure in any of them.  (any_overflow[-6], [-5] = misc[0], misc[1]: bound
+  // violations and wave-log overflow, final here because every earlier kernel of this search has completed.)
+  if (mode == 1 && tid == 0) {
+    if (overflow[q]) { atomicOr(any_overflow, 1u); atomicOr(any_overflow + 6, 1u); }
+    if (q == 0) {
+      const uint32_t viol = any_overflow[-6], logovf = any_overflow[-5];
+      if (viol) atomicAdd(any_overflow + 7, viol);
+      if (logovf) atomicOr(any_overflow + 8, 1u);
+    }
+  }
   Cand* mine = cand + static_cast<uint64_t>(q) * cap;
   if (m <= 512) {
     // short list (the usual case): rank every entry against all others with broadcast LDS reads -- one pass,

@@ -259,3 +259,166 @@ __global__ __launch_bounds__(256, 1) void refine_l2_lds_kernel(const void* __res
 }
 
 }  // namespace nvdbhip
+
+namespace nvdbhip {
+
+// ------------------------------------------------------------------------------------------------
+// refine, version 3 (fp16 rows, dim in {256, 512, 768}): WHOLE rows per request, four lanes per row.
+//
+// v2 above fetches a row as six 256-byte pieces that are microseconds apart: every piece re-opens the row's DRAM page,
+// and the gather saturated at 4.3 TB/s with FETCH_SIZE == algorithmic bytes (profiles/r02_refine_v2_*.txt) -- the
+// memory system was the limit, not the kernel's issue rate.  Here a wave asks for 16 whole rows back to back
+// (per row one 1-KB direct-to-LDS load with a SCALAR row base + one 512-byte remainder shared with a second row),
+// the access shape MI355X_MICROARCH.md measures at 5.5-5.8 TB/s for random 1-2 KB rows.
+//
+//   * workgroup = 3 waves = one query; two workgroups per CU (2 x 3 x 24 KB of row slots), no workgroup barrier in the
+//     loop: a wave waits only for its own loads (s_waitcnt vmcnt) -- while it computes, the other five keep
+//     ~120 KB per CU in flight.
+//   * lane (r, c) = lane/4, lane%4 handles row r of the step and accumulator c of the reference kernel
+//     (cuda_refine.cu:326-382: half2 pair p feeds accumulator p & 3, dx then dy, pairs in ascending order):
+//     it reads pair 4i + c of every 16-byte piece i with ds_read2_b32 at STATIC offsets and keeps its own 2 x dim/8
+//     query elements in registers for the whole query.  dx = q - float(x) is ONE v_fma_mix_f32 (x read as the low /
+//     high half of the packed register, times -1.0, plus q: a single rounding, the same bits as the subtraction).
+//   * LDS image: row r's first KB at r * 1040 (16 bytes of padding: the 8 rows of a half-wave hit 8 x 4 distinct
+//     banks), remainders of rows j and j + 8 in one KB at j * 1040 (the two rows are read by different half-waves).
+//   * d = (a0 + a1) + (a2 + a3) by two quad shuffles, then the same wavefront-resident top-K as v1/v2.
+// Results are bit-identical to v1/v2 and to the oracle's restatement (tests + tools_dev/fuzz_refine.py).
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// 16 bytes per lane HBM -> LDS, global address = sbase + voff + IMM, LDS address = lds_off (wave-uniform) + lane * 16
+template <int IMM>
+__device__ __forceinline__ void glds16_imm(uint32_t voff, const void* sbase, uint32_t lds_off) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 offset:%4\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_off), "s"(sbase), "n"(IMM) : "memory");
+}
+
+// q - float(half) in ONE instruction: v_fma_mix_f32 reads the low / high half of the packed register as fp16, multiplies
+// by -1.0 (exact) and adds q with a single rounding -- the same bits as cvt + v_sub_f32 (hipcc folds the C++ form of
+// this fma back into cvt + sub, hence the asm).
+__device__ __forceinline__ float q_minus_half_lo(uint32_t xpk, float q) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(xpk), "v"(q));
+  return r;
+}
+__device__ __forceinline__ float q_minus_half_hi(uint32_t xpk, float q) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(xpk), "v"(q));
+  return r;
+}
+
+constexpr int REFINE3_WAVES = 3, REFINE3_ROWS = 16, REFINE3_BLOCK = 1040;
+template <int DIM> constexpr int refine3_slot_bytes() {
+  constexpr int RB = DIM * 2, NA = RB / 1024, HAS_B = (RB % 1024) ? 1 : 0;
+  return REFINE3_ROWS * NA * REFINE3_BLOCK + HAS_B * (REFINE3_ROWS / 2) * REFINE3_BLOCK;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(64 * REFINE3_WAVES) void refine_l2_rows_kernel(const void* __restrict__ rows, uint64_t n, const float* __restrict__ queries,
+                                                                            const uint32_t* __restrict__ cand, uint32_t R, uint32_t K,
+                                                                            uint32_t* __restrict__ out_ids, float* __restrict__ out_dist) {
+  constexpr int RB = DIM * 2;                       // row bytes
+  constexpr int NA = RB / 1024;                     // whole 1-KB pieces per row
+  constexpr int REM = RB % 1024;                    // 0 or 512: remainder, two rows per piece
+  static_assert(REM == 0 || REM == 512, "row bytes must be a multiple of 512");
+  static_assert(NA <= 1, "rows longer than 1536 bytes take the v2 kernel");
+  constexpr int NPAIR = DIM / 8;                    // pairs per lane = 16-byte pieces per row
+  constexpr int SLOT = refine3_slot_bytes<DIM>();
+  constexpr int BOFF = REFINE3_ROWS * NA * REFINE3_BLOCK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float lds_d[REFINE3_WAVES][64];
+  __shared__ uint32_t lds_id[REFINE3_WAVES][64];
+  __shared__ uint32_t lds_cnt[REFINE3_WAVES];
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane >> 2, c = lane & 3;
+  const uint32_t* __restrict__ cq = cand + static_cast<uint64_t>(q) * R;
+  char* myslot = smem + wave * SLOT;
+  const uint32_t lds_mine = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(myslot)));
+  const char* gbase = static_cast<const char*>(rows);
+
+  // this lane's query elements: pairs c, c + 4, c + 8, ... (two floats each), resident for the whole query
+  float2 qv[NPAIR];
+  {
+    const float2* qp = reinterpret_cast<const float2*>(queries + static_cast<uint64_t>(q) * DIM) + c;
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) qv[i] = qp[4 * i];
+  }
+
+  WaveTopKMin tk;
+  tk.d = 1e30f; tk.id = 0xFFFFFFFFu; tk.cnt = 0; tk.thr_d = 1e30f; tk.thr_id = 0xFFFFFFFFu;
+
+  const uint32_t voffA = static_cast<uint32_t>(lane) * 16u;                                 // piece A: lane l <- bytes [16 l, 16 l + 16) of the row
+  const uint32_t lane_lo = static_cast<uint32_t>(lane & 31) * 16u + NA * 1024u;             // piece B: 32 lanes per row, after the A part
+  const char* rdA = myslot + r * REFINE3_BLOCK + c * 4;                                     // this lane's read bases
+  const char* rdB = myslot + BOFF + (r & 7) * REFINE3_BLOCK + (r >> 3) * 512 + c * 4;
+
+  uint32_t idx = wave * REFINE3_ROWS + (lane & 15);
+  uint32_t ids_next = (idx < R) ? cq[idx] : 0xFFFFFFFFu;
+  for (uint32_t s0 = wave * REFINE3_ROWS; s0 < R; s0 += REFINE3_WAVES * REFINE3_ROWS) {
+    const uint32_t ids = ids_next;                  // lanes 0..15 (and their copies in 16..63): candidate of row lane & 15
+    idx += REFINE3_WAVES * REFINE3_ROWS;
+    ids_next = (idx < R) ? cq[idx] : 0xFFFFFFFFu;   // next step's ids travel while this step's rows do
+    // ---- issue: 16 whole rows (rows j and j + 8 together: they share the remainder piece) ----
+#pragma unroll
+    for (int j = 0; j < REFINE3_ROWS / 2; ++j) {
+      const uint32_t sid0 = readlane_u(ids, j), sid1 = readlane_u(ids, j + 8);
+      const bool ok0 = (sid0 != 0xFFFFFFFFu) && (static_cast<uint64_t>(sid0) < n);         // cuda_refine.cu:437
+      const bool ok1 = (sid1 != 0xFFFFFFFFu) && (static_cast<uint64_t>(sid1) < n);
+      const uint64_t off0 = static_cast<uint64_t>(ok0 ? sid0 : 0u) * RB;                   // skipped candidates: row 0, dropped below
+      const uint64_t off1 = static_cast<uint64_t>(ok1 ? sid1 : 0u) * RB;
+      if constexpr (NA == 1) {                       // wave-uniform branches
+        if (ok0) glds16_imm<0>(voffA, gbase + off0, lds_mine + j * REFINE3_BLOCK);
+        if (ok1) glds16_imm<0>(voffA, gbase + off1, lds_mine + (j + 8) * REFINE3_BLOCK);
+      }
+      if constexpr (REM != 0) {
+        const uint64_t o = (lane < 32 ? off0 : off1) + lane_lo;                            // the two rows are read by different half-waves
+        if (ok0 || ok1) glds16_v(gbase + o, lds_mine + BOFF + j * REFINE3_BLOCK);
+      }
+    }
+    const uint32_t my_id = static_cast<uint32_t>(__shfl(static_cast<int>(ids), r));
+    const bool valid = (my_id != 0xFFFFFFFFu) && (static_cast<uint64_t>(my_id) < n);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- consume: accumulator c of row r ----
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+      const char* src = (i < NA * 64) ? rdA + i * 16 : rdB + (i - NA * 64) * 16;
+      const uint32_t x = *reinterpret_cast<const uint32_t*>(src);                          // half2 pair (x[2p], x[2p+1])
+      const float dx = q_minus_half_lo(x, qv[i].x);
+      const float dy = q_minus_half_hi(x, qv[i].y);
+      acc = __builtin_fmaf(dx, dx, acc);
+      acc = __builtin_fmaf(dy, dy, acc);
+    }
+    const float s1 = acc + __shfl_xor(acc, 1);      // a0 + a1 | a2 + a3
+    const float d = s1 + __shfl_xor(s1, 2);         // (a0 + a1) + (a2 + a3): the same bits in all four lanes
+    unsigned long long m = __ballot(valid && c == 0 && wmin_accepts(tk, K, d, my_id));
+    while (m) {
+      const int L = __builtin_ctzll(m);
+      m &= m - 1;
+      const float cd = readlane_f(d, L);
+      const uint32_t cid = readlane_u(my_id, L);
+      if (wmin_accepts(tk, K, cd, cid)) wmin_insert(tk, K, cd, cid, lane);
+    }
+  }
+  lds_d[wave][lane] = tk.d; lds_id[wave][lane] = tk.id;
+  if (lane == 0) lds_cnt[wave] = tk.cnt;
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w = 1; w < REFINE3_WAVES; ++w) {
+    const uint32_t cn = lds_cnt[w];
+    for (uint32_t j = 0; j < cn; ++j) {
+      const float cd = lds_d[w][j];
+      const uint32_t cid = lds_id[w][j];
+      if (wmin_accepts(tk, K, cd, cid)) wmin_insert(tk, K, cd, cid, lane);
+    }
+  }
+  if (static_cast<uint32_t>(lane) < K) {
+    const bool have = static_cast<uint32_t>(lane) < tk.cnt;
+    out_ids[static_cast<uint64_t>(q) * K + lane] = have ? tk.id : 0xFFFFFFFFu;
+    if (out_dist) out_dist[static_cast<uint64_t>(q) * K + lane] = have ? tk.d : 1e30f;
+  }
+}
+
+}  // namespace nvdbhip

@@ -24,6 +24,7 @@
 
 #include "kernels_exact.h"
 #include "kernels_filter.h"
+#include "kernels_largek.h"
 #include "kernels_refine.h"
 #include "nvdb_common.h"
 
@@ -34,6 +35,7 @@ namespace {
 std::string g_create_err;
 
 constexpr uint32_t SELECT_MAX_CAP = 8192;     // 64 KB of LDS in select_kernel
+constexpr uint32_t WAVE_KMAX = 64;            // k the wavefront-resident top-k lists hold (entry j in lane j)
 constexpr float FILTER_REL_F16 = 7.5e-4f;     // |filter - reference| <= REL * ||q|| * max||x||   (DESIGN.md "error bound")
 
 struct DevBuf {
@@ -78,6 +80,8 @@ struct nvdb_hip_ctx {
   // grow-only workspace
   DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, prog;
   DevBuf rq, rcand, rout_ids, rout_dist;           // refine
+  DevBuf lk_scores, lk_sel, lk_hist, lk_state;     // any-k path (kernels_largek.h): score matrix of a query sub-batch, selected keys, radix state
+  int64_t opt_largek_budget_mb = 8192;             // HBM the any-k path may use for its score matrix
 
   // options
   int64_t opt_path = 0, opt_chunk0 = 512, opt_cap = 0, opt_min_filter_batch = 1, opt_growth = 0;   // opt_growth 0 = automatic
@@ -96,7 +100,7 @@ struct nvdb_hip_ctx {
   int64_t opt_sibling_sync = 1;                    // 1: co-streaming workgroups rendezvous every 8 tiles (L2 sharing)
   int64_t opt_f32_shadow = 1;                      // 1: fp32 corpora get an fp16 shadow copy for the MFMA filter
   int64_t opt_mfma_boot = 1;                       // 1: threshold bootstrap on the matrix cores (fp16 corpora)
-  int64_t opt_refine_v2 = 1;                       // 1: LDS-staged coalesced gather in the refine kernel
+  int64_t opt_refine_v2 = 2;                       // refine kernel: 0 lane per row, 1 column chunks through LDS, 2 whole rows through LDS (fp16 d = 256/512/768; else 1)
   int64_t opt_mfma16 = 1;                          // 1: use the 16x16x32 MFMA build for 256-query tiles
   std::set<const void*> lds_attr_set;              // kernels whose dynamic-LDS limit was raised on this device
 };
@@ -658,6 +662,89 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
   return fail(c, NVDB_ERR_UNSUPPORTED, "filter kernel: unsupported dim");
 }
 
+// ---- any k (kernels_largek.h): exact scores of a query sub-batch -> radix select of the k-th key -> sort -> emit ----------
+template <int QG>
+nvdb_status launch_scores_exact_qg(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uint32_t nq, float* out, uint64_t ld) {
+  const uint32_t n = static_cast<uint32_t>(c->n);
+  const dim3 grid(std::min<uint32_t>((n + 255u) / 256u, 8u * static_cast<uint32_t>(c->num_cu)), (nq + QG - 1) / QG);
+  const bool al = aligned_rows(c->dtype, c->dim);
+  const size_t lds = static_cast<size_t>(QG) * ((c->dim + 3u) & ~3u) * 4;
+#define NVDB_LAUNCH_SC(DT, AL) scores_exact_kernel<DT, QG, AL><<<grid, 256, lds, s>>>(c->rows, c->scales, c->dim, n, q32, nq, out, ld)
+  if (c->dtype == NVDB_DTYPE_F32) { if (al) NVDB_LAUNCH_SC(DT_F32, true); else NVDB_LAUNCH_SC(DT_F32, false); }
+  else if (c->dtype == NVDB_DTYPE_F16) { if (al) NVDB_LAUNCH_SC(DT_F16, true); else NVDB_LAUNCH_SC(DT_F16, false); }
+  else { if (al) NVDB_LAUNCH_SC(DT_I8, true); else NVDB_LAUNCH_SC(DT_I8, false); }
+#undef NVDB_LAUNCH_SC
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+nvdb_status search_largek(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint32_t nq, uint32_t k, uint64_t* dev_out_ids, float* dev_out_scores) {
+  const uint32_t n = static_cast<uint32_t>(c->n);
+  const uint32_t k_eff = static_cast<uint32_t>(std::min<uint64_t>(k, c->n));
+  const uint64_t ld = (static_cast<uint64_t>(n) + 63u) & ~63ull;
+  uint32_t K2 = 2;
+  while (K2 < k_eff) K2 <<= 1;
+  const size_t qstride_bytes = static_cast<size_t>((c->dim + 3u) & ~3u) * 4;
+  if (qstride_bytes > 60 * 1024) return fail(c, NVDB_ERR_UNSUPPORTED, "dim too large for the exact kernel's LDS query staging (max ~14800)");
+  uint32_t QG = nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1));
+  while (QG > 1 && QG * qstride_bytes > 60 * 1024) QG >>= 1;
+  // queries per sub-batch: what the score matrix + key lists may take of HBM
+  const size_t per_query = ld * 4 + static_cast<size_t>(K2) * 8;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+  const size_t have = c->lk_scores.bytes + c->lk_sel.bytes;                     // already ours: counts as available
+  const size_t budget = std::min<size_t>(static_cast<size_t>(c->opt_largek_budget_mb) << 20, (free_b + have) / 2);
+  uint32_t QB = static_cast<uint32_t>(std::min<size_t>(nq, std::max<size_t>(1, budget / per_query)));
+  if (QB >= QG) QB = QB / QG * QG;
+  if (per_query > free_b + have) return fail(c, NVDB_ERR_HIP, "any-k path: not enough free HBM for one query's score row");
+  nvdb_status st;
+  if ((st = ensure(c, c->lk_scores, static_cast<size_t>(QB) * ld * 4))) return st;
+  if ((st = ensure(c, c->lk_sel, static_cast<size_t>(QB) * K2 * 8))) return st;
+  if ((st = ensure(c, c->lk_hist, static_cast<size_t>(QB) * 256 * 4))) return st;
+  if ((st = ensure(c, c->lk_state, static_cast<size_t>(QB) * sizeof(RadixState)))) return st;
+  float* scores = static_cast<float*>(c->lk_scores.p);
+  unsigned long long* sel = static_cast<unsigned long long*>(c->lk_sel.p);
+  uint32_t* hist = static_cast<uint32_t*>(c->lk_hist.p);
+  RadixState* rst = static_cast<RadixState*>(c->lk_state.p);
+  if (K2 <= 8192) {
+    const void* fn = reinterpret_cast<const void*>(bitonic_lds_kernel);
+    if (!c->lds_attr_set.count(fn)) {
+      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+      c->lds_attr_set.insert(fn);
+    }
+  }
+  for (uint32_t q0 = 0; q0 < nq; q0 += QB) {
+    const uint32_t b = std::min(QB, nq - q0);
+    const float* q = dev_q + static_cast<size_t>(q0) * c->dim;
+    radix_init_kernel<<<b, 256, 0, s>>>(rst, hist, b, k_eff);
+    switch (QG) {
+      case 8: st = launch_scores_exact_qg<8>(c, s, q, b, scores, ld); break;
+      case 4: st = launch_scores_exact_qg<4>(c, s, q, b, scores, ld); break;
+      case 2: st = launch_scores_exact_qg<2>(c, s, q, b, scores, ld); break;
+      default: st = launch_scores_exact_qg<1>(c, s, q, b, scores, ld); break;
+    }
+    if (st) return st;
+    const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>((n + 255u) / 256u, (8u * static_cast<uint32_t>(c->num_cu) + b - 1) / b));
+    for (int pass = 0; pass < 8; ++pass) {
+      radix_hist_kernel<<<dim3(G, b), 256, 0, s>>>(scores, ld, n, pass, rst, hist);
+      radix_pick_kernel<<<b, 256, 0, s>>>(rst, hist);
+    }
+    collect_kernel<<<dim3(G, b), 256, 0, s>>>(scores, ld, n, rst, sel, K2, k_eff);
+    if (K2 <= 8192) bitonic_lds_kernel<<<b, 256, static_cast<size_t>(K2) * 8, s>>>(sel, K2);
+    else
+      for (uint32_t size = 2; size <= K2; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1)
+          bitonic_global_step_kernel<<<dim3((K2 / 2 + 255) / 256, b), 256, 0, s>>>(sel, K2, size, stride);
+    emit_kernel<<<dim3((k + 255) / 256, b), 256, 0, s>>>(sel, K2, scores, ld, k_eff, k, c->row_base,
+                                                        reinterpret_cast<unsigned long long*>(dev_out_ids) + static_cast<size_t>(q0) * k,
+                                                        dev_out_scores + static_cast<size_t>(q0) * k);
+    HIPCHK(c, hipGetLastError());
+  }
+  c->stats.chunks = (nq + QB - 1) / QB;
+  c->stats.rows_scanned = c->n;
+  return NVDB_OK;
+}
+
 hipEvent_t get_event(nvdb_hip_ctx* c, size_t idx) {
   while (c->ev_pool.size() <= idx) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
   return c->ev_pool[idx];
@@ -700,6 +787,11 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   c->last_nq = nq; c->last_cap = cap; c->last_filter = (path == 2);
   c->ev_filter.clear();
 
+  if (k_eff > WAVE_KMAX) {
+    // beyond the wavefront-resident lists (k <= 64): the any-k path (scores -> radix select -> sort)
+    c->stats.path = 3; c->last_filter = false;
+    return search_largek(c, s, dev_q, nq, k, dev_out_ids, dev_out_scores);
+  }
   if (path == 1) {
     if ((st = launch_scan_exact(c, s, 0, n, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
     c->stats.chunks = 1; c->stats.rows_scanned = c->n;
@@ -845,7 +937,7 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   free_corpus(c);
   for (DevBuf* b : {&c->q32, &c->q16, &c->qscale, &c->qinv, &c->ebound, &c->slack, &c->thr, &c->cnt, &c->overflow, &c->cand,
-                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->prog, &c->qdelta, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist})
+                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->prog, &c->qdelta, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist, &c->lk_scores, &c->lk_sel, &c->lk_hist, &c->lk_state})
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& k : c->klaunch) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
@@ -966,7 +1058,8 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "tile_permute") { c->opt_tile_permute = value ? 1 : 0; }
   else if (k == "rescore8") { c->opt_rescore8 = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
-  else if (k == "refine_v2") { c->opt_refine_v2 = value ? 1 : 0; }
+  else if (k == "refine_v2") { c->opt_refine_v2 = value < 0 ? 0 : (value > 2 ? 2 : value); }
+  else if (k == "largek_budget_mb") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "largek_budget_mb must be >= 1"); c->opt_largek_budget_mb = value; }
   else if (k == "chunk_growth") { if (value != 0 && (value < 2 || value > 64)) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be 0 (automatic) or in [2,64]"); c->opt_growth = value; }
   else if (k == "min_filter_batch") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "min_filter_batch must be >= 1"); c->opt_min_filter_batch = value; }
   else return fail(c, NVDB_ERR_INVALID, "unknown option: " + k);
@@ -977,7 +1070,6 @@ static nvdb_status search_args(nvdb_hip_ctx* c, const void* q, uint32_t nq, uint
   if (!c) return NVDB_ERR_INVALID;
   if (!c->rows || c->n == 0) return fail(c, NVDB_ERR_NO_CORPUS, "Empty base");
   if (nq > 0 && k > 0 && (!q || !oi || !os)) return fail(c, NVDB_ERR_INVALID, q ? "null output" : "Null query");
-  if (k > NVDB_HIP_FLAT_KMAX) return fail(c, NVDB_ERR_INVALID, "k exceeds NVDB_HIP_FLAT_KMAX (64)");
   return NVDB_OK;
 }
 
@@ -997,9 +1089,15 @@ nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   HIPCHK(c, hipSetDevice(c->device));
   // caller has synchronised its stream; read the self-check words
   std::vector<uint32_t> ovf(c->last_nq);
-  uint32_t misc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t misc[16] = {0};
   if (c->last_nq) HIPCHK(c, hipMemcpy(ovf.data(), c->overflow.p, c->last_nq * 4, hipMemcpyDeviceToHost));
-  if (c->misc.p) HIPCHK(c, hipMemcpy(misc, c->misc.p, 32, hipMemcpyDeviceToHost));
+  if (c->misc.p) {
+    HIPCHK(c, hipMemcpy(misc, c->misc.p, 64, hipMemcpyDeviceToHost));
+    const uint32_t zero[3] = {0, 0, 0};             // sticky words (select_kernel): what ANY search since the last check found
+    if (misc[12] | misc[13] | misc[14]) HIPCHK(c, hipMemcpy(static_cast<uint32_t*>(c->misc.p) + 12, zero, 12, hipMemcpyHostToDevice));
+  }
+  c->stats.sticky_overflow = (misc[12] | misc[14]) ? 1u : 0u;
+  c->stats.sticky_violations = misc[13];
   c->stats.i8_stage1_tiles = misc[4]; c->stats.i8_stage2_blocks = misc[5];
   uint32_t nov = 0;
   for (uint32_t v : ovf) nov += v ? 1u : 0u;
@@ -1028,6 +1126,8 @@ nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   if (stats) *stats = c->stats;
   if (misc[0]) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated (bound_violations > 0)");
   if (nov) return fail(c, NVDB_ERR_INTERNAL, "candidate list overflow: re-run these queries with option path=1");
+  if (misc[13]) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated in an earlier search since the last check");
+  if (misc[12] | misc[14]) return fail(c, NVDB_ERR_INTERNAL, "candidate list overflow in an earlier search since the last check");
   return NVDB_OK;
 }
 
@@ -1052,7 +1152,8 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     // a single-query search at N = 1M).  Small query blocks go up through the same staging buffer.
     const size_t ob_ids = static_cast<size_t>(nq) * k * 8, ob_sc = static_cast<size_t>(nq) * k * 4;
     const size_t q_stage = qbytes <= 64 * 1024 ? qbytes : 0;
-    const size_t need = 64 + ob_ids + ob_sc + q_stage;
+    const bool stage_out = ob_ids + ob_sc <= (static_cast<size_t>(16) << 20);     // very large k: results go straight to the caller's buffers
+    const size_t need = 64 + (stage_out ? ob_ids + ob_sc : 0) + q_stage;
     if (c->pinned_bytes < need) {
       if (c->pinned) (void)hipHostFree(c->pinned);
       c->pinned = nullptr; c->pinned_bytes = 0;
@@ -1061,7 +1162,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     }
     char* pin = static_cast<char*>(c->pinned);
     uint32_t* pin_status = reinterpret_cast<uint32_t*>(pin);
-    char* pin_ids = pin + 64; char* pin_sc = pin_ids + ob_ids; char* pin_q = pin_sc + ob_sc;
+    char* pin_ids = pin + 64; char* pin_sc = pin_ids + (stage_out ? ob_ids : 0); char* pin_q = pin_sc + (stage_out ? ob_sc : 0);
     HIPCHK(c, hipEventRecord(e0, s));
     HIPCHK(c, hipMemsetAsync(static_cast<char*>(c->q32.p) + qbytes, 0, 8 * static_cast<size_t>(c->dim) * 4, s));
     if (q_stage) { std::memcpy(pin_q, queries, qbytes); HIPCHK(c, hipMemcpyAsync(c->q32.p, pin_q, qbytes, hipMemcpyHostToDevice, s)); }
@@ -1074,8 +1175,8 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     HIPCHK(c, hipEventRecord(e2, s));
     auto fetch = [&]() -> nvdb_status {
       HIPCHK(c, hipMemcpyAsync(pin_status, c->misc.p, 32, hipMemcpyDeviceToHost, s));
-      HIPCHK(c, hipMemcpyAsync(pin_ids, oi, ob_ids, hipMemcpyDeviceToHost, s));
-      HIPCHK(c, hipMemcpyAsync(pin_sc, os, ob_sc, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipMemcpyAsync(stage_out ? static_cast<void*>(pin_ids) : static_cast<void*>(out_ids), oi, ob_ids, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipMemcpyAsync(stage_out ? static_cast<void*>(pin_sc) : static_cast<void*>(out_scores), os, ob_sc, hipMemcpyDeviceToHost, s));
       HIPCHK(c, hipEventRecord(e3, s));
       HIPCHK(c, hipStreamSynchronize(s));
       return NVDB_OK;
@@ -1100,6 +1201,8 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
         if ((st = search_core(c, s, dq, nq, k, oi, os, 1, false))) return st;
         if ((st = fetch())) return st;
       }
+      // handled here: do not leave the sticky self-check words set for a later nvdb_hip_search_check
+      HIPCHK(c, hipMemsetAsync(static_cast<uint32_t*>(c->misc.p) + 12, 0, 12, s));
       c->stats = part;
     } else {
       part.i8_stage1_tiles = pin_status[4]; part.i8_stage2_blocks = pin_status[5];
@@ -1109,8 +1212,10 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
       c->stats = part;
       c->stats_lazy = c->last_filter;                 // candidates: read back on demand
     }
-    std::memcpy(out_ids, pin_ids, ob_ids);
-    std::memcpy(out_scores, pin_sc, ob_sc);
+    if (stage_out) {
+      std::memcpy(out_ids, pin_ids, ob_ids);
+      std::memcpy(out_scores, pin_sc, ob_sc);
+    }
     if (timing) {
       (void)hipEventElapsedTime(&timing->h2d_ms, e0, e1);
       (void)hipEventElapsedTime(&timing->kernel_ms, e1, e2);
@@ -1154,6 +1259,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
         if ((st = search_core(c, s, dq, b, k, oi, os, 1, false))) return st;
         HIPCHK(c, hipStreamSynchronize(s));
       }
+      HIPCHK(c, hipMemsetAsync(static_cast<uint32_t*>(c->misc.p) + 12, 0, 12, s));     // handled: clear the sticky self-check words
     }
     total.path = std::max(total.path, part.path);
     total.chunks += part.chunks; total.rows_scanned += part.rows_scanned; total.candidates += part.candidates;
@@ -1413,6 +1519,23 @@ static nvdb_status refine_args(nvdb_hip_ctx* c, const void* q, const void* cand,
 static nvdb_status launch_refine(nvdb_hip_ctx* c, hipStream_t s, const float* dq, const uint32_t* dc, uint32_t Q, uint32_t R,
                                  uint32_t K, uint32_t* doi, float* dod) {
   const bool al = aligned_rows(c->dtype, c->dim);
+  // v3 (whole rows per request, four lanes per row): fp16 rows of 512 / 1024 / 1536 bytes
+  if (c->opt_refine_v2 >= 2 && c->dtype == NVDB_DTYPE_F16 && (c->dim == 768 || c->dim == 512 || c->dim == 256)) {
+#define NVDB_REFINE3(D)                                                                                                        \
+    {                                                                                                                          \
+      constexpr size_t lds = static_cast<size_t>(REFINE3_WAVES) * refine3_slot_bytes<D>();                                      \
+      const void* fn = reinterpret_cast<const void*>(refine_l2_rows_kernel<D>);                                                 \
+      if (!c->lds_attr_set.count(fn)) {                                                                                        \
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                 \
+        c->lds_attr_set.insert(fn);                                                                                            \
+      }                                                                                                                        \
+      refine_l2_rows_kernel<D><<<Q, 64 * REFINE3_WAVES, lds, s>>>(c->rows, c->n, dq, dc, R, K, doi, dod);                       \
+    }
+    if (c->dim == 768) NVDB_REFINE3(768) else if (c->dim == 512) NVDB_REFINE3(512) else NVDB_REFINE3(256)
+#undef NVDB_REFINE3
+    HIPCHK(c, hipGetLastError());
+    return NVDB_OK;
+  }
   // v2 (coalesced gather through LDS): whole 16-byte steps only (f16: dim % 8 == 0, f32: dim % 4 == 0)
   if (al && c->opt_refine_v2 && static_cast<uint64_t>(c->dim) * bpe_of(c->dtype) >= 256) {
     constexpr size_t lds = 4 * 2 * 64 * 256;

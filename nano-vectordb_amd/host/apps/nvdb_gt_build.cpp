@@ -1,11 +1,14 @@
 // nvdb_gt_build -- exact top-k ids of every query -> .gtbin (reference apps/nvdb_gt_build.cpp:22-129).
-// GT_MODE = gpu (default here when a GPU is present) | omp | st | async | pool ; WARMUP as in the reference.
+// GT_MODE = omp (default, as in the reference) | gpu | st | async | pool ; WARMUP as in the reference.
+// Loader errors escape like the reference's (uncaught std::runtime_error); a failure of the GPU path (no device, out of
+// memory ...) is reported and ends the program with exit code 7.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,7 +26,7 @@ int main(int argc, char** argv) {
   }
   const uint32_t k = static_cast<uint32_t>(std::stoul(argv[3]));
   const char* m = std::getenv("GT_MODE");
-  const std::string mode = m ? m : (nvdb_hip_device_count() > 0 ? "gpu" : "omp");
+  const std::string mode = m ? m : "omp";                     // reference default (apps/nvdb_gt_build.cpp:33-35); GT_MODE=gpu selects the MI355X path
   nvdb::VectorDataset base, query;
   base.load(argv[1]);
   query.load(argv[2]);
@@ -39,6 +42,7 @@ int main(int argc, char** argv) {
     return true;
   };
   if (mode == "gpu") {
+   try {
     nvdb::FlatIndexHIP idx(&base);
     const uint64_t B = 1024;
     for (uint64_t q0 = 0; q0 < Q; q0 += B) {
@@ -47,6 +51,10 @@ int main(int argc, char** argv) {
       const size_t ke = res.size() / b;
       for (uint32_t i = 0; i < b; ++i) if (!store(q0 + i, res.data() + i * ke, ke)) return 5;
     }
+  } catch (const std::exception& e) {
+    std::cerr << "nvdb_gt_build: GT_MODE=gpu failed: " << e.what() << "\n";
+    return 7;
+   }
   } else {
     nvdb::FlatIndex st(&base);
     nvdb::FlatIndexOMP omp(&base);
@@ -73,3 +81,4 @@ int main(int argc, char** argv) {
   std::cout << "Wrote GT: " << argv[4] << " (header=64B, payload=" << ids.size() * sizeof(uint32_t) << " bytes)\n";
   return 0;
 }
+

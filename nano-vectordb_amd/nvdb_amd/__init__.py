@@ -17,7 +17,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnvdb_hip.so")
 
 DT_F32, DT_F16, DT_I8 = 1, 2, 3
-FLAT_KMAX = 64
 REFINE_KMAX = 64
 _NP_OF = {DT_F32: np.float32, DT_F16: np.uint16, DT_I8: np.int8}
 
@@ -49,7 +48,8 @@ class Timing(C.Structure):
 class ScanStats(C.Structure):
     _fields_ = [("path", C.c_uint32), ("chunks", C.c_uint32), ("rows_scanned", C.c_uint64), ("candidates", C.c_uint64),
                 ("overflow_queries", C.c_uint32), ("bound_violations", C.c_uint32), ("filter_kernel_ms", C.c_float),
-                ("other_kernel_ms", C.c_float), ("i8_stage1_tiles", C.c_uint32), ("i8_stage2_blocks", C.c_uint32)]
+                ("other_kernel_ms", C.c_float), ("i8_stage1_tiles", C.c_uint32), ("i8_stage2_blocks", C.c_uint32),
+                ("sticky_overflow", C.c_uint32), ("sticky_violations", C.c_uint32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

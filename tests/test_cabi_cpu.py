@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in nvdb_hip.h but not exported"
     assert declared == set(nvdb_amd.EXPORTS), declared ^ set(nvdb_amd.EXPORTS)
-    assert lib.nvdb_hip_abi_version() == 1
+    assert lib.nvdb_hip_abi_version() == 2
 
 
 def test_timing_struct_mirrors_reference_layout():

@@ -96,8 +96,9 @@ def test_single_query_and_edge_arguments(ctx, oracle):
     assert np.array_equal(ids, oid) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
     ids0, sc0 = ctx.search_batch(queries, 0)                 # k == 0 -> empty (flat_index.cpp:18)
     assert ids0.shape == (len(queries), 0)
-    with pytest.raises(nvdb_amd.NvdbError):
-        ctx.search_batch(queries, 65)                        # > NVDB_HIP_FLAT_KMAX
+    i65, s65 = ctx.search_batch(queries, 65)                 # k is bounded by N only (flat_index.cpp:24): the any-k path
+    o65, os65 = oracle.flat_topk(base32, po.DT_F32, queries, 65)
+    assert ctx.stats()["path"] == 3 and np.array_equal(i65, o65) and np.array_equal(s65.view(np.uint32), os65.view(np.uint32))
     idx = nvdb_amd.FlatIndexHIP(base32, po.DT_F32)
     r = idx.search_topk_dot(queries[1], 3)
     assert [i for i, _ in r] == oid[0:0].tolist() or len(r) == 3
@@ -549,6 +550,45 @@ def test_refine_argument_conventions(ctx, oracle):
         ctx.refine_l2_topk(q, np.zeros((2, 4), dtype=np.uint32), 3)              # int8 base unsupported (nvdb_ivf_eval.cpp:519-525)
 
 
+# ----------------------------------------------------------------------------- any k (reference: k clamped to N only)
+@pytest.mark.parametrize("tag", ["f32", "f16", "i8"])
+@pytest.mark.parametrize("name,k", [("main768", 65), ("main768", 100), ("main768", 1000), ("main768", 3000), ("main768", 5000),
+                                    ("ties64", 100), ("ties64", 600), ("tail100", 699)])
+def test_any_k_matches_oracle(ctx, oracle, name, k, tag):
+    """k > 64 (src/flat_index.cpp:24 clamps k to N and nothing else): scores of every row in the reference's fp32 order,
+    radix select of the k-th (score desc, id asc) key, sort.  Golden-case inputs incl. exact duplicates (ties64),
+    k == N and k > N."""
+    base32, queries = make_case_inputs(name)
+    base, dt, scales = _as_dtype(oracle, base32, tag)
+    ctx.upload_corpus(base, dt, scales)
+    ids, sc = ctx.search_batch(queries, k)
+    assert ctx.stats()["path"] == 3
+    oid, osc = oracle.flat_topk(base, dt, queries, k, scales)
+    assert ids.shape == oid.shape == (len(queries), min(k, len(base)))
+    for qi in range(len(queries)):
+        allsc = oracle.scores(base, dt, queries[qi], scales)
+        assert_topk_equal(ids[qi], sc[qi], oid[qi], osc[qi], score_of=lambda i: allsc[i], what=f"anyk/{name}/{tag}/k{k}/q{qi}")
+        order = np.lexsort((ids[qi], -sc[qi].astype(np.float64)))
+        assert np.array_equal(order, np.arange(ids.shape[1])), "canonical (score desc, id asc) order"
+
+
+def test_any_k_large_lists_sorted_in_global_memory(oracle):
+    """k = 20 000 of 50 000 rows (lists longer than the 8192 entries LDS sorts), 11 queries in sub-batches of 4 (tiny
+    score-matrix budget), and the device-buffer entry point."""
+    n, d, nq, k = 50_000, 128, 11, 20_000
+    c = nvdb_amd.HipContext(0)
+    c.generate_corpus(SEED + 5, n, d, nvdb_amd.DT_F16)
+    base, _ = nvdb_amd.synth_corpus(SEED + 5, 0, n, d, nvdb_amd.DT_F16)
+    queries = nvdb_amd.synth_rows_f32(SEED + 6, 0, nq, d)
+    c.set_option("largek_budget_mb", 1)
+    ids, sc = c.search_batch(queries, k)
+    st = c.stats()
+    assert st["path"] == 3 and st["chunks"] >= 3, st
+    oid, osc = oracle.flat_topk(base, po.DT_F16, queries, k)
+    assert np.array_equal(ids, oid) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    c.close()
+
+
 # ----------------------------------------------------------------------------- BASELINE full sizes: size-independent properties
 @pytest.mark.parametrize("dtype,tag", [(nvdb_amd.DT_F16, "f16"), (nvdb_amd.DT_I8, "i8")])
 def test_full_size_10M_properties(oracle, dtype, tag):
@@ -715,7 +755,7 @@ def test_refine_config5_full_size(oracle):
     oid, odist = oracle.refine(base, po.DT_F16, queries[sub], cand[sub], K, mode=0)
     cid, cdist = oracle.refine(base, po.DT_F16, queries[sub], cand[sub], K, mode=1)
     results = {}
-    for v2 in (1, 0):
+    for v2 in (2, 1, 0):
         ctx.set_option("refine_v2", v2)
         ids, dist, t = ctx.refine_l2_topk(queries, cand, K, want_timing=True)
         results[v2] = (ids, dist)
@@ -728,8 +768,9 @@ def test_refine_config5_full_size(oracle):
         assert (ids[8] == n - 1).all() and (dist[8] == 0.0).all()      # forty copies of the last row, which is query 8 itself
         assert (dist[::5, 0] == 0.0).all() and np.array_equal(ids[::5, 0], cand[::5, 17])      # the self-matches win
         assert t.kernel_ms > 0 and t.R == R and t.K == K
-    ctx.set_option("refine_v2", 1)
-    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1].view(np.uint32), results[1][1].view(np.uint32))
+    ctx.set_option("refine_v2", 2)
+    for a in (0, 1):
+        assert np.array_equal(results[a][0], results[2][0]) and np.array_equal(results[a][1].view(np.uint32), results[2][1].view(np.uint32)), a
     ctx.close()
 
 
@@ -748,7 +789,7 @@ def test_refine_f32_rows_beyond_4GiB(oracle):
     local = np.where(cand == 0xFFFFFFFF, cand, cand - np.uint32(hot_lo))
     oid, odist = oracle.refine(tail, po.DT_F32, queries, local, K, mode=0)
     oid = np.where(oid == 0xFFFFFFFF, oid, oid + np.uint32(hot_lo))
-    for v2 in (1, 0):
+    for v2 in (2, 1, 0):
         ctx.set_option("refine_v2", v2)
         ids, dist = ctx.refine_l2_topk(queries, cand, K)
         assert np.array_equal(ids, oid) and np.array_equal(dist.view(np.uint32), odist.view(np.uint32)), v2

@@ -11,10 +11,16 @@ queries = nvdb_amd.synth_rows_f32(20240614, 0, Q, D)
 rs = np.random.RandomState(1)
 cand = rs.randint(0, N, size=(Q, R)).astype(np.uint32)
 cand[rs.rand(Q, R) < 0.01] = 0xFFFFFFFF
-best = None
-for it in range(4):
-    ids, dist, t = ctx.refine_l2_topk(queries, cand, K, want_timing=True)
-    if best is None or t.kernel_ms < best.kernel_ms: best = t
+per_kernel = {}
+for v2 in [int(x) for x in os.environ.get("REFINE_V2", "2,1").split(",")]:
+    ctx.set_option("refine_v2", v2)
+    best = None
+    for it in range(4):
+        ids, dist, t = ctx.refine_l2_topk(queries, cand, K, want_timing=True)
+        if best is None or t.kernel_ms < best.kernel_ms: best = t
+    per_kernel[f"refine_v2={v2}"] = best.kernel_ms
+ctx.set_option("refine_v2", int(os.environ.get("REFINE_V2", "2,1").split(",")[0]))
+ids, dist, best = ctx.refine_l2_topk(queries, cand, K, want_timing=True)
 # parity on a slice against the oracle's restated kernel order (bit-exact) and CPU double order
 sub = slice(0, 64)
 rows = {}
@@ -28,4 +34,4 @@ ok = np.array_equal(uniq[oid], ids[sub]) and np.array_equal(od.view(np.uint32), 
 gb = Q * R * 0.99 * D * 2 / 1e9
 print(json.dumps({"config": f"refine N={N} Q={Q} R={R} K={K} f16", "kernel_ms": best.kernel_ms, "h2d_ms": best.h2d_ms, "d2h_ms": best.d2h_ms,
                   "us_per_query_kernel": best.kernel_ms * 1e3 / Q, "gather_GBps": gb / (best.kernel_ms * 1e-3), "hbm_frac": gb / (best.kernel_ms * 1e-3) / 8000.0,
-                  "parity_vs_oracle_slice": bool(ok)}))
+                  "parity_vs_oracle_slice": bool(ok), "kernel_ms_by_variant": per_kernel}))

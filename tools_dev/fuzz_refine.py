@@ -22,7 +22,7 @@ for ci in range(cases):
     cand = rs.randint(0, n, size=(Q, R)).astype(np.uint32)
     cand[rs.rand(Q, R) < 0.02] = 0xFFFFFFFF
     cand[rs.rand(Q, R) < 0.02] = n + 5                        # out of range: skipped (cuda_refine.cu:437)
-    for v2 in (1, 0):
+    for v2 in (2, 1, 0):
         ctx.set_option("refine_v2", v2)
         ids, dist = ctx.refine_l2_topk(q, cand, K)
         oi, od = orc.refine(base, po.DT_F16 if tag == "f16" else po.DT_F32, q, cand, K, mode=0)
@@ -30,6 +30,6 @@ for ci in range(cases):
         if not ok:
             fails += 1
             print(f"FAIL case {ci}: {tag} n={n} dim={dim} Q={Q} R={R} K={K} refine_v2={v2}", flush=True)
-    ctx.set_option("refine_v2", 1)
+    ctx.set_option("refine_v2", 2)
 print(f"refine fuzz seed {seed}: {cases} cases x 2 kernels, {fails} failures, {time.time() - t0:.1f} s", flush=True)
 sys.exit(1 if fails else 0)
