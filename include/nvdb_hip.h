@@ -168,7 +168,7 @@ nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint3
 /* Tunables (defaults are what bench.py measures; the table with meanings is in INTEGRATION.md section 4b):
  * "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "chunk_growth", "cand_cap", "min_filter_batch", "mfma_boot",
  * "mfma16", "waves8", "sibling_sync", "sync_every", "sync_lead", "tile_permute", "f32_shadow" (set before the upload),
- * "i8_wide", "rescore8", "refine_v2", "largek_budget_mb" (HBM for the any-k path's score matrix), "time_kernels" (1: start / stop events attached to every launch of the dominant
+ * "i8_wide", "rescore8", "refine_v2", "refine_pinned" (reference CUDA_PINNED: pinned host staging in nvdb_hip_refine_l2_topk), "largek_budget_mb" (HBM for the any-k path's score matrix), "time_kernels" (1: start / stop events attached to every launch of the dominant
  * kernel).  Unknown key -> NVDB_ERR_INVALID. */
 nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* ctx, const char* key, int64_t value);
 
@@ -177,23 +177,6 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* ctx, const char* key, int64_t valu
  * (rows * dim * bytes/elem).  Synchronises on the recorded events.  bench.py's roofline uses it. */
 nvdb_status nvdb_hip_collect_kernel_times(nvdb_hip_ctx* ctx, uint32_t* launches, double* total_ms,
                                           double* total_flops, double* total_bytes);
-
-/* Developer aid, not part of the drop-in surface: time ablation builds of the fp16 d=768 filter kernel (thresholds
- * +inf, results discarded) on the resident corpus with the query workspace of the previous search (nq > 128).
- * Variants: 0 normal, 1 no direct-to-LDS loads, 2 = 1 + no barrier, 3 no MFMA, 5 no LDS reads, 6-9 fragment ring
- * 6/8/3/12, 10 L2-resident corpus. */
-nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* ctx, int variant, uint32_t nq, uint32_t reps, float* ms_per_launch);
-
-/* Developer aid: the clock the chip holds inside the production fp16 d=768 filter kernel.  Launches a diagnostic
- * build (identical code + one s_memtime / s_memrealtime stamp pair around the tile loop of every workgroup) back to
- * back for `seconds`, then reports out4 = { ms per launch (last 8), median, min, max over workgroups of
- * delta(s_memtime) / delta(s_memrealtime) x 100 MHz in GHz }.  variant: 0 = the production loop; timing-only
- * ablations 1 = no direct-to-LDS loads, 5 = no LDS reads, 15 = neither.  Same preconditions as the call above. */
-nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* ctx, int variant, uint32_t nq, float seconds, float* out4);
-
-/* Developer aid (host only, no GPU): the physical tile the filter kernels stream for logical tile g of a corpus of n_tiles
- * tiles -- a bijection of [0, n_tiles) (identity below 64 tiles).  tests/test_cabi_cpu.py checks that property. */
-uint32_t nvdb_permuted_tile(uint32_t g, uint32_t n_tiles);
 
 /* ---------------------------------------------------------------------------------------------
  * exact-L2 refine (rerank of R candidates per query) -- replaces nvdb::cuda_l2_topk_batch

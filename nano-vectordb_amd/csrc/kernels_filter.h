@@ -1104,7 +1104,10 @@ __device__ __forceinline__ int imax3(int a, int b, int c) {
 // ------------------------------------------------------------------------------------------------
 // MB = 32-row blocks per tile: 2 -> 64-row tiles (a 52 KB stage, three of them) halve the per-tile costs (barrier,
 // loop-top scalar code, rendezvous, MFMA drain) per row; 1 -> 32-row tiles, five stages (debug / A-B only).
-template <int DIM, int NB = 2, int RING = 6, bool SYNC = false, int MB = 2>
+// STAMP / VAR: diagnostic builds only (libnvdb_hip_dev.so, nvdb_hip_debug_clock_i8; results are wrong for VAR != 0):
+// STAMP = s_memtime / s_memrealtime around the tile loop (written behind the rendezvous counters); VAR 1 = never run
+// stage 2 (no lo-plane pass), 2 = no stage-1 test either (MFMAs + stream only), 3 = 2 + no per-tile barrier.
+template <int DIM, int NB = 2, int RING = 6, bool SYNC = false, int MB = 2, bool STAMP = false, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
     const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
@@ -1199,13 +1202,15 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
 
   uint32_t sync_strikes = 0;
+  uint64_t stamp_c = 0, stamp_r = 0;
+  if constexpr (STAMP) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
       if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(prog + static_cast<uint64_t>(stream) * 8, qt, t, sync_lead, sync_strikes, lane);
     }
     // my pieces of tile t have landed once all but the newest NSTAGE-2 tiles' loads are complete
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (PPW + 1)) : "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (VAR < 3) __builtin_amdgcn_s_barrier();
     const uint32_t next_row0 = tile_row0(t + NSTAGE - 1), next_buf = (t + NSTAGE - 1) % NSTAGE;
     const char* stage = smem + (t % NSTAGE) * STAGE_BYTES;
     if (!wave_has_queries) {
@@ -1252,6 +1257,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(acc[mb][nb]));
 
+    if constexpr (VAR >= 2) continue;
     // ---- stage 1: can any of my NB x 16 hi-plane values H_r * scale_r reach its first-stage threshold? ----------
     // (exact per value: cvt + mul, then a max tree per block and one compare; a cheaper bound such as
     //  max(H) * max(scale) lets a quarter of the tiles through, and a tile costs what its slowest wave costs)
@@ -1272,6 +1278,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
       }
     if (!__builtin_amdgcn_ballot_w64(dall >= 0.f)) continue;
     ++n_stage1;
+    if constexpr (VAR == 1) continue;
     const uint32_t row0 = tile_row0(t);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -1310,6 +1317,13 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
           }
         }
       }
+  }
+  if constexpr (STAMP) {
+    const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c, dr = __builtin_amdgcn_s_memrealtime() - stamp_r;
+    if (wave == 0 && lane == 0) {
+      uint64_t* out = reinterpret_cast<uint64_t*>(prog + static_cast<uint64_t>(gridDim.x) * 8) + static_cast<uint64_t>(blockIdx.x) * 2;
+      out[0] = dc; out[1] = dr;
+    }
   }
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(prog + static_cast<uint64_t>(stream) * 8 + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (stage_counts && lane == 0 && (n_stage1 | n_stage2)) { atomicAdd(stage_counts, n_stage1); atomicAdd(stage_counts + 1, n_stage2); }

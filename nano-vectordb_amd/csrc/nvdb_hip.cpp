@@ -8,6 +8,9 @@
 // There is NO CPU fallback anywhere in this file: without a working HIP device every entry point
 // that computes returns NVDB_ERR_HIP.
 #include "../../include/nvdb_hip.h"
+#ifdef NVDB_HIP_DEV
+#include "../../include/nvdb_hip_dev.h"
+#endif
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -81,6 +84,9 @@ struct nvdb_hip_ctx {
   DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, prog;
   DevBuf rq, rcand, rout_ids, rout_dist;           // refine
   DevBuf lk_scores, lk_sel, lk_hist, lk_state;     // any-k path (kernels_largek.h): score matrix of a query sub-batch, selected keys, radix state
+  int64_t opt_refine_pinned = 0;                   // refine host call: stage queries / candidates / results through pinned host buffers (reference CUDA_PINNED)
+  void* rpinned = nullptr;                         // ... [queries | candidates | out ids | out dist]
+  size_t rpinned_bytes = 0;
   int64_t opt_largek_budget_mb = 8192;             // HBM the any-k path may use for its score matrix
 
   // options
@@ -276,7 +282,11 @@ nvdb_status launch_select(nvdb_hip_ctx* c, hipStream_t s, uint32_t nq, uint32_t 
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_MAX_CAP * sizeof(Cand)));
     c->lds_attr_set.insert(fn);
   }
-  select_kernel<<<nq, 256, cap * sizeof(Cand), s>>>(static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap, k, slack,
+  // the bitonic branch pads a list to the next power of two >= its length (<= cap): size the LDS for that
+  uint32_t cap2 = 1;
+  while (cap2 < cap) cap2 <<= 1;
+  static_assert(SELECT_MAX_CAP * sizeof(Cand) <= 64 * 1024 && (SELECT_MAX_CAP & (SELECT_MAX_CAP - 1)) == 0, "select_kernel LDS");
+  select_kernel<<<nq, 256, cap2 * sizeof(Cand), s>>>(static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap, k, slack,
                                                    static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->overflow.p), mode,
                                                    c->row_base, reinterpret_cast<unsigned long long*>(out_ids), out_scores, out_k,
                                                    static_cast<uint32_t*>(c->misc.p) + 6);
@@ -943,6 +953,7 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
   for (auto& k : c->klaunch) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
   for (hipEvent_t e : c->kl_pool) (void)hipEventDestroy(e);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->rpinned) (void)hipHostFree(c->rpinned);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1059,6 +1070,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "rescore8") { c->opt_rescore8 = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
   else if (k == "refine_v2") { c->opt_refine_v2 = value < 0 ? 0 : (value > 2 ? 2 : value); }
+  else if (k == "refine_pinned") { c->opt_refine_pinned = value ? 1 : 0; }
   else if (k == "largek_budget_mb") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "largek_budget_mb must be >= 1"); c->opt_largek_budget_mb = value; }
   else if (k == "chunk_growth") { if (value != 0 && (value < 2 || value > 64)) return fail(c, NVDB_ERR_INVALID, "chunk_growth must be 0 (automatic) or in [2,64]"); c->opt_growth = value; }
   else if (k == "min_filter_batch") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "min_filter_batch must be >= 1"); c->opt_min_filter_batch = value; }
@@ -1307,6 +1319,7 @@ nvdb_status nvdb_hip_collect_kernel_times(nvdb_hip_ctx* c, uint32_t* launches, d
   return NVDB_OK;
 }
 
+#ifdef NVDB_HIP_DEV
 // Developer aid (not part of the drop-in surface): time ablation builds of the filter kernel on the
 // resident fp16 d=768 corpus with the query workspace left by the previous path-2 search.  Thresholds
 // are +inf (no survivors), so only the streaming/MFMA machinery is timed.
@@ -1446,6 +1459,78 @@ nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* c, int variant, uint32_t nq, floa
   return NVDB_OK;
 }
 
+
+nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, float seconds, float* out4) {
+  if (!c || !out4) return NVDB_ERR_INVALID;
+  if (!c->rows || c->dtype != NVDB_DTYPE_I8 || c->dim != 768 || !c->q16.p || !c->opt_i8_wide) return fail(c, NVDB_ERR_UNSUPPORTED, "debug: run a path-2 search on an int8 d=768 corpus first");
+  if (nq <= 128 || nq > (c->last_nq + 255u) / 256u * 256u) return fail(c, NVDB_ERR_UNSUPPORTED, "debug: 128 < nq <= the last search's padded batch");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t QT = (nq + 255) / 256, nq_pad = QT * 256;
+  const uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
+  if (nwg == 0 || (nwg & 7u) || ((nwg >> 3) % QT)) return fail(c, NVDB_ERR_UNSUPPORTED, "debug: batch does not map onto the XCD-aware grid");
+  // thresholds: the ones the last search ended with (realistic stage-1 / stage-2 rates for the production variant)
+  const size_t prog_bytes = static_cast<size_t>(nwg) * 8 * 4, stamp_bytes = static_cast<size_t>(nwg) * 16;
+  nvdb_status st;
+  if ((st = ensure(c, c->prog, std::max(prog_bytes + stamp_bytes, static_cast<size_t>(PROG_SLOTS) * c->num_cu * 8 * 4)))) return st;
+  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+  constexpr size_t lds = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + 4 * 1024);
+  const uint32_t n_al = static_cast<uint32_t>(c->n / I8W_TILE_ROWS * I8W_TILE_ROWS);
+  const signed char* qhi = static_cast<const signed char*>(c->q16.p);
+  const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * 768;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  const auto t_start = std::chrono::steady_clock::now();
+  float ms = 0.f;
+  const uint32_t burst = 8;
+#define NVDB_CLK_I8(V)                                                                                                           \
+  {                                                                                                                              \
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_i8w_kernel<768, 2, 6, true, 2, true, V>),                 \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                           \
+    for (uint32_t r = 0; r < burst; ++r) {                                                                                       \
+      HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, prog_bytes, c->stream));                                                         \
+      filter_i8w_kernel<768, 2, 6, true, 2, true, V><<<nwg, 256, lds, c->stream>>>(                                              \
+          filter_rows_i8(c), filter_scales_i8(c), 0, n_al, qhi, qlo, nq, QT, static_cast<const float*>(c->thr.p),                \
+          static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<const float*>(c->qdelta.p),  \
+          static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap, I8W_TILE_ROWS), static_cast<uint32_t*>(c->prog.p),        \
+          static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), nullptr);                       \
+    }                                                                                                                            \
+  }
+  for (;;) {
+    const bool last = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_start).count() >= seconds;
+    if (last) HIPCHK(c, hipEventRecord(e0, c->stream));
+    switch (variant) {
+      case 0: NVDB_CLK_I8(0) break;
+      case 1: NVDB_CLK_I8(1) break;
+      case 2: NVDB_CLK_I8(2) break;
+      case 3: NVDB_CLK_I8(3) break;
+      default: return fail(c, NVDB_ERR_INVALID, "debug: unknown variant");
+    }
+    HIPCHK(c, hipGetLastError());
+    if (last) {
+      HIPCHK(c, hipEventRecord(e1, c->stream));
+      HIPCHK(c, hipEventSynchronize(e1));
+      HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+      ms /= static_cast<float>(burst);
+      break;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+#undef NVDB_CLK_I8
+  std::vector<uint64_t> stamps(static_cast<size_t>(nwg) * 2);
+  HIPCHK(c, hipMemcpy(stamps.data(), static_cast<const char*>(c->prog.p) + prog_bytes, stamp_bytes, hipMemcpyDeviceToHost));
+  std::vector<float> ghz;
+  for (uint32_t w = 0; w < nwg; ++w)
+    if (stamps[2 * w + 1]) ghz.push_back(static_cast<float>(static_cast<double>(stamps[2 * w]) / static_cast<double>(stamps[2 * w + 1]) * 0.1));
+  std::sort(ghz.begin(), ghz.end());
+  out4[0] = ms;
+  out4[1] = ghz.empty() ? 0.f : ghz[ghz.size() / 2];
+  out4[2] = ghz.empty() ? 0.f : ghz.front();
+  out4[3] = ghz.empty() ? 0.f : ghz.back();
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return NVDB_OK;
+}
+#endif  // NVDB_HIP_DEV
+
 nvdb_status nvdb_hip_get_stats(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   if (!c || !stats) return NVDB_ERR_INVALID;
   if (c->stats_lazy) {                             // the small-call path skips this read-back; do it now
@@ -1584,35 +1669,63 @@ nvdb_status nvdb_hip_refine_l2_topk(nvdb_hip_ctx* c, const float* queries, const
   if ((st = ensure(c, c->rout_ids, ob))) return st;
   if ((st = ensure(c, c->rout_dist, ob))) return st;
   hipEvent_t e0 = get_event(c, 56), e1 = get_event(c, 57), e2 = get_event(c, 58), e3 = get_event(c, 59);
+  // optional pinned staging (reference: CUDA_PINNED, src/cuda_refine.cu:875, 902-914): inputs are packed into pinned host
+  // buffers BEFORE the timed region, the asynchronous copies then run at the link's rate instead of through the runtime's
+  // pageable bounce buffers; results come back into pinned memory and are copied out after the synchronisation.
+  const void* h_q = queries;
+  const void* h_c = cand_ids;
+  void* h_oi = out_ids;
+  void* h_od = out_dist;
+  if (c->opt_refine_pinned) {
+    const size_t need = qb + cb + 2 * ob;
+    if (c->rpinned_bytes < need) {
+      if (c->rpinned) (void)hipHostFree(c->rpinned);
+      c->rpinned = nullptr; c->rpinned_bytes = 0;
+      HIPCHK(c, hipHostMalloc(&c->rpinned, need, hipHostMallocDefault));
+      c->rpinned_bytes = need;
+    }
+    char* pin = static_cast<char*>(c->rpinned);
+    std::memcpy(pin, queries, qb);
+    std::memcpy(pin + qb, cand_ids, cb);
+    h_q = pin; h_c = pin + qb; h_oi = pin + qb + cb; h_od = pin + qb + cb + ob;
+  }
   HIPCHK(c, hipEventRecord(e0, s));
-  HIPCHK(c, hipMemcpyAsync(c->rq.p, queries, qb, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(c->rcand.p, cand_ids, cb, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->rq.p, h_q, qb, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->rcand.p, h_c, cb, hipMemcpyHostToDevice, s));
   HIPCHK(c, hipEventRecord(e1, s));
   if ((st = launch_refine(c, s, static_cast<const float*>(c->rq.p), static_cast<const uint32_t*>(c->rcand.p), Q, R, K,
                           static_cast<uint32_t*>(c->rout_ids.p), out_dist ? static_cast<float*>(c->rout_dist.p) : nullptr)))
     return st;
   HIPCHK(c, hipEventRecord(e2, s));
-  HIPCHK(c, hipMemcpyAsync(out_ids, c->rout_ids.p, ob, hipMemcpyDeviceToHost, s));
-  if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, c->rout_dist.p, ob, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(h_oi, c->rout_ids.p, ob, hipMemcpyDeviceToHost, s));
+  if (out_dist) HIPCHK(c, hipMemcpyAsync(h_od, c->rout_dist.p, ob, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipEventRecord(e3, s));
   HIPCHK(c, hipStreamSynchronize(s));
+  if (c->opt_refine_pinned) {
+    std::memcpy(out_ids, h_oi, ob);
+    if (out_dist) std::memcpy(out_dist, h_od, ob);
+  }
   if (timing) {
     (void)hipEventElapsedTime(&timing->h2d_ms, e0, e1);
     (void)hipEventElapsedTime(&timing->kernel_ms, e1, e2);
     (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
     timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
-    timing->threads = 256; timing->nwarps = 4; timing->K = K; timing->R = R;
-    timing->shmem_bytes = 4 * 64 * 8 + 16;
+    const bool rows_kernel = c->opt_refine_v2 >= 2 && c->dtype == NVDB_DTYPE_F16 && (c->dim == 768 || c->dim == 512 || c->dim == 256);
+    timing->threads = rows_kernel ? 64 * REFINE3_WAVES : 256; timing->nwarps = rows_kernel ? REFINE3_WAVES : 4; timing->K = K; timing->R = R;
+    timing->shmem_bytes = rows_kernel ? static_cast<size_t>(REFINE3_WAVES) * (c->dim == 768 ? refine3_slot_bytes<768>() : c->dim == 512 ? refine3_slot_bytes<512>() : refine3_slot_bytes<256>())
+                                      : (c->opt_refine_v2 ? 4 * 2 * 64 * 256 : 4 * 64 * 8 + 16);
   }
   return NVDB_OK;
 }
 
 // ---- host helpers -----------------------------------------------------------------------------------
+#ifdef NVDB_HIP_DEV
 uint32_t nvdb_permuted_tile(uint32_t g, uint32_t n_tiles) {
   uint32_t mul, mask;
   perm_params(n_tiles, mul, mask);
   return perm_tile_raw(g, mul, mask, n_tiles);
 }
+#endif
 
 void nvdb_synth_rows_f32(uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t dim, float* out) {
   std::vector<int32_t> raw(dim);

@@ -8,7 +8,7 @@
 //
 //   nvdb_cuda_refine_eval <base.vecbin> <query.vecbin> <k>
 //   env: REFINE_K (default 1024)   CAND_PATH (raw uint32[Q*REFINE_K]; default: synthetic, see below)
-//        CUDA_REFINE_WARMUP (1)    CUDA_RETURN_DIST (1)   GIT_SHA
+//        CUDA_REFINE_WARMUP (1)    CUDA_RETURN_DIST (1)   CUDA_PINNED (0)   GIT_SHA
 // Synthetic candidates (FAISS absent): per query the exact top-min(64,REFINE_K) by dot (== L2 for
 // normalised data) found with the GPU flat scan, filled up to REFINE_K with distinct pseudo-random ids,
 // shuffled with a seeded generator; 1 % of the slots are set to 0xFFFFFFFF to exercise the skip path.
@@ -122,7 +122,7 @@ int main(int argc, char** argv) {
   std::cout << "refine_recall_gpu_vs_cpu=" << recall_sum / double(Q) << " identical_rows=" << exact_rows << "/" << Q << " cpu_refine_ms_total=" << cpu_ms << "\n";
   std::cout << "RESULT refine_k=" << refine_k << " Q=" << Q << " k=" << k << " cuda_refine=1 refine_enabled=1 refine_backend=cuda"
             << " refine_ms_total=" << t.total_ms << " refine_ms_per_q=" << t.total_ms / double(Q)
-            << " kernel_mode=wave64 cuda_pinned=0 cuda_return_dist=" << env_int("CUDA_RETURN_DIST", 1) << " git_rev=" << env_str("GIT_SHA", "NA")
+            << " kernel_mode=wave64 cuda_pinned=" << env_int("CUDA_PINNED", 0) << " cuda_return_dist=" << env_int("CUDA_RETURN_DIST", 1) << " git_rev=" << env_str("GIT_SHA", "NA")
             << " refine_h2d_ms=" << t.h2d_ms << " refine_kernel_ms=" << t.kernel_ms << " refine_d2h_ms=" << t.d2h_ms
             << " refine_kernel_ms_per_q=" << (Q ? t.kernel_ms / double(Q) : 0.0)
             << " cuda_threads=" << t.threads << " cuda_nwarps=" << t.nwarps << " cuda_shmem_bytes=" << t.shmem_bytes

@@ -22,7 +22,8 @@ struct CudaRefineTiming {
 
 // base_dtype: 1 = fp32, 2 = fp16.  The device copy of the base is cached across calls, keyed by
 // (pointer, N, D, dtype), like the reference (src/cuda_refine.cu:188-203).  Errors: std::exit with the
-// reference's codes (1 runtime error, 2 bad dtype, 3 K > 64).  Env: CUDA_RETURN_DIST=0 -> ids only.
+// reference's codes (1 runtime error, 2 bad dtype, 3 K > 64).  Env: CUDA_RETURN_DIST=0 -> ids only; CUDA_PINNED=1 -> the
+// call's host buffers are staged through pinned memory (reference src/cuda_refine.cu:875, 902-914).
 void cuda_l2_topk_batch(const void* base_ptr, uint32_t base_dtype, uint64_t N, uint32_t D, const float* queries_f32,
                         const uint32_t* cand_ids, uint32_t Q, uint32_t R, uint32_t K, std::vector<uint32_t>& out_topk_ids,
                         std::vector<float>& out_topk_dist, CudaRefineTiming* timing = nullptr);

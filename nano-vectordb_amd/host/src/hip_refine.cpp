@@ -39,6 +39,8 @@ void cuda_l2_topk_batch(const void* base_ptr, uint32_t base_dtype, uint64_t N, u
     if (nvdb_hip_upload_corpus(g.ctx, base_ptr, nullptr, N, D, base_dtype, 0) != NVDB_OK) die("H2D base(cache)", 1);
     g.base = base_ptr; g.n = N; g.d = D; g.dt = base_dtype;
   }
+  const char* pn = std::getenv("CUDA_PINNED");                                  // :875 pinned host staging of the call's buffers
+  if (nvdb_hip_set_option(g.ctx, "refine_pinned", (pn && std::atoi(pn) != 0) ? 1 : 0) != NVDB_OK) die("set_option", 1);
   const char* rd = std::getenv("CUDA_RETURN_DIST");
   const bool want_dist = !(rd && std::atoi(rd) == 0);
   out_ids.assign(static_cast<size_t>(Q) * K, 0xFFFFFFFFu);

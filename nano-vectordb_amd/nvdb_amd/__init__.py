@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnvdb_hip.so")
+DEV_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnvdb_hip_dev.so")   # developer build: + nvdb_hip_debug_* (include/nvdb_hip_dev.h)
 
 DT_F32, DT_F16, DT_I8 = 1, 2, 3
 REFINE_KMAX = 64
@@ -24,10 +25,12 @@ EXPORTS = [
     "nvdb_hip_abi_version", "nvdb_hip_device_count", "nvdb_hip_create", "nvdb_hip_destroy", "nvdb_hip_last_error",
     "nvdb_hip_upload_corpus", "nvdb_hip_adopt_corpus", "nvdb_hip_generate_corpus", "nvdb_hip_corpus_info",
     "nvdb_hip_download_rows", "nvdb_hip_search_batch", "nvdb_hip_search_batch_dev", "nvdb_hip_search_check",
-    "nvdb_hip_get_stats", "nvdb_hip_collect_kernel_times", "nvdb_hip_debug_filter_variant", "nvdb_hip_debug_clock", "nvdb_permuted_tile", "nvdb_hip_merge_topk_dev", "nvdb_hip_merge_topk_strided_dev", "nvdb_merge_topk_host", "nvdb_hip_set_option",
+    "nvdb_hip_get_stats", "nvdb_hip_collect_kernel_times", "nvdb_hip_merge_topk_dev", "nvdb_hip_merge_topk_strided_dev", "nvdb_merge_topk_host", "nvdb_hip_set_option",
     "nvdb_hip_refine_l2_topk", "nvdb_hip_refine_l2_topk_dev", "nvdb_synth_rows_f32", "nvdb_f32_to_f16",
     "nvdb_quantize_i8_rows",
 ]
+# only in libnvdb_hip_dev.so; the product library must NOT export them (tests/test_cabi_cpu.py)
+DEV_EXPORTS = ["nvdb_hip_debug_filter_variant", "nvdb_hip_debug_clock", "nvdb_hip_debug_clock_i8", "nvdb_permuted_tile"]
 
 
 class NvdbError(RuntimeError):
@@ -56,6 +59,7 @@ class ScanStats(C.Structure):
 
 
 _lib = None
+_dev_lib = None
 
 
 def _share_hip_runtime_with_torch():
@@ -73,16 +77,7 @@ def _share_hip_runtime_with_torch():
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
-def load_library():
-    """Load libnvdb_hip.so; raises (never falls back) when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C nano-vectordb_amd` "
-                          "(python -c 'import __graft_entry__ as g; g.build()')")
-    _share_hip_runtime_with_torch()
-    L = C.CDLL(LIB_PATH)
+def _bind(L, dev):
     vp, u32, u64, i64, f32p = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64, C.POINTER(C.c_float)
     L.nvdb_hip_abi_version.restype = C.c_int
     L.nvdb_hip_device_count.restype = C.c_int
@@ -102,10 +97,6 @@ def load_library():
     L.nvdb_hip_get_stats.argtypes = [vp, C.POINTER(ScanStats)]
     L.nvdb_hip_collect_kernel_times.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                 C.POINTER(C.c_double)]
-    L.nvdb_hip_debug_filter_variant.argtypes = [vp, C.c_int, u32, u32, f32p]
-    L.nvdb_hip_debug_clock.argtypes = [vp, C.c_int, u32, C.c_float, f32p]
-    L.nvdb_permuted_tile.argtypes = [u32, u32]
-    L.nvdb_permuted_tile.restype = u32
     L.nvdb_hip_merge_topk_dev.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp]
     L.nvdb_hip_merge_topk_strided_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, u32, u32, u32, vp, vp, vp]
     L.nvdb_merge_topk_host.argtypes = [vp, vp, u32, u32, u32, vp, vp]
@@ -119,12 +110,39 @@ def load_library():
     L.nvdb_quantize_i8_rows.argtypes = [vp, u64, u32, vp, vp]
     L.nvdb_quantize_i8_rows.restype = None
     for name in EXPORTS:
-        fn = getattr(L, name)
-        if fn.restype is C.c_int and name.startswith(("nvdb_hip_", "nvdb_merge")) and name not in (
-                "nvdb_hip_abi_version", "nvdb_hip_device_count"):
-            fn.restype = C.c_int
-    _lib = L
+        getattr(L, name)
+    if dev:
+        L.nvdb_hip_debug_filter_variant.argtypes = [vp, C.c_int, u32, u32, f32p]
+        L.nvdb_hip_debug_clock.argtypes = [vp, C.c_int, u32, C.c_float, f32p]
+        L.nvdb_hip_debug_clock_i8.argtypes = [vp, C.c_int, u32, C.c_float, f32p]
+        L.nvdb_permuted_tile.argtypes = [u32, u32]
+        L.nvdb_permuted_tile.restype = u32
     return L
+
+
+def load_library():
+    """Load libnvdb_hip.so (the product library); raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C nano-vectordb_amd` "
+                          "(python -c 'import __graft_entry__ as g; g.build()')")
+    _share_hip_runtime_with_torch()
+    _lib = _bind(C.CDLL(LIB_PATH), dev=False)
+    return _lib
+
+
+def load_dev_library():
+    """Load libnvdb_hip_dev.so: the same ABI plus the developer entry points (tools_dev/ only)."""
+    global _dev_lib
+    if _dev_lib is not None:
+        return _dev_lib
+    if not os.path.exists(DEV_LIB_PATH):
+        raise ImportError(f"{DEV_LIB_PATH} is missing: build it with `make -C nano-vectordb_amd`")
+    _share_hip_runtime_with_torch()
+    _dev_lib = _bind(C.CDLL(DEV_LIB_PATH), dev=True)
+    return _dev_lib
 
 
 # ------------------------------------------------------------------------------- host-side helpers (no GPU)
@@ -178,8 +196,8 @@ def merge_topk_host(ids, scores):
 class HipContext:
     """One GPU: resident corpus + workspace (nvdb_hip_ctx)."""
 
-    def __init__(self, device=0):
-        self.lib = load_library()
+    def __init__(self, device=0, dev=False):
+        self.lib = load_dev_library() if dev else load_library()   # dev=True: a context of the developer build (tools_dev/)
         h = C.c_void_p()
         st = self.lib.nvdb_hip_create(device, C.byref(h))
         if st:

@@ -32,6 +32,22 @@ def test_header_symbols_all_exported(lib):
     assert lib.nvdb_hip_abi_version() == 2
 
 
+def test_product_library_carries_only_the_drop_in_surface(lib):
+    """Developer aids (timing-only ablation launchers, in-kernel clock stamps) live in libnvdb_hip_dev.so behind
+    include/nvdb_hip_dev.h: the product library exports none of them, the dev library all of them plus the whole ABI."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", nvdb_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b(nvdb_[a-z0-9_]+)\b", syms))
+    assert exported == set(nvdb_amd.EXPORTS), exported ^ set(nvdb_amd.EXPORTS)
+    assert not any("debug" in e for e in exported)
+    dev = nvdb_amd.load_dev_library()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "nvdb_hip_dev.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(nvdb_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(nvdb_amd.DEV_EXPORTS), declared ^ set(nvdb_amd.DEV_EXPORTS)
+    for name in list(nvdb_amd.EXPORTS) + list(nvdb_amd.DEV_EXPORTS):
+        assert hasattr(dev, name), name
+
+
 def test_timing_struct_mirrors_reference_layout():
     # nvdb::CudaRefineTiming (reference include/nvdb/cuda_refine.h:7-22): 4 floats, 4 u32, size_t, u32, 6 doubles
     names = [f for f, _ in nvdb_amd.Timing._fields_]
@@ -105,7 +121,7 @@ def test_merge_topk_host_canonical_order(lib):
 def test_tile_permutation_is_a_bijection():
     """The filter kernels stream logical tile g from physical tile nvdb_permuted_tile(g, T); every tile must be visited
     exactly once for any corpus size (odd multiplier modulo the next power of two, cycle-walked into range)."""
-    lib = nvdb_amd.load_library()
+    lib = nvdb_amd.load_dev_library()                          # a developer aid: only the dev build exports it
     for T in (1, 2, 63, 64, 65, 100, 1023, 1024, 1025, 1876, 3751, 4097, 65536, 78125, 312500):
         img = np.fromiter((lib.nvdb_permuted_tile(g, T) for g in range(T)), dtype=np.uint32, count=T)
         assert img.max() == T - 1 and len(np.unique(img)) == T, T

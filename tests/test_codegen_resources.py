@@ -1,0 +1,108 @@
+"""Guards against silent codegen drift in the hand-scheduled kernels (no GPU needed: hipcc cross-compiles gfx950).
+
+The filter kernels keep their stationary operand in AGPRs through inline asm at __launch_bounds__(..., 1 or 2), count
+their own vmcnt, hard-code s[88:95] in the sibling rendezvous and rely on explicit wait states: a hipcc bump that
+spills, renumbers or drops occupancy would still pass the parity tests on small inputs while losing the performance
+(or, with scratch, the timing assumptions).  `make -C nano-vectordb_amd asm` dumps the per-kernel resource usage
+(-Rpass-analysis=kernel-resource-usage) and the ISA; this test reads both."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "nano-vectordb_amd")
+
+
+@pytest.fixture(scope="module")
+def codegen():
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    subprocess.check_call(["make", "-C", PKG, "asm"], stdout=subprocess.DEVNULL)
+    usage, cur = {}, None
+    for line in open(os.path.join(PKG, "build", "resource_usage.txt")):
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            usage[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+) \[-Rpass", line)
+        if m and cur:
+            usage[cur][m.group(1).strip()] = m.group(2)
+    names = subprocess.run(["c++filt"] + list(usage), capture_output=True, text=True, check=True).stdout.splitlines()
+    by_name = {}
+    for mangled, pretty in zip(usage, names):
+        short = re.sub(r"\(.*", "", pretty).replace("void nvdbhip::", "").replace("nvdbhip::", "")
+        u = usage[mangled]
+        by_name[short if short != mangled else mangled] = dict(
+            mangled=mangled, sgpr=int(u["TotalSGPRs"]), vgpr=int(u["VGPRs"]), agpr=int(u["AGPRs"]), scratch=int(u["ScratchSize"]),
+            occ=int(u["Occupancy"]), sspill=int(u["SGPRs Spill"]), vspill=int(u["VGPRs Spill"]))
+    asm = open(os.path.join(PKG, "build", "nvdb_hip.s")).read()
+    return by_name, asm
+
+
+def _body(asm, mangled):
+    a = asm.index(f"\n{mangled}:")
+    return asm[a:asm.index("s_endpgm", a)]
+
+
+def _find(by_name, *parts):
+    hits = [k for k in by_name if all(p in k or p in by_name[k]["mangled"] for p in parts)]
+    assert len(hits) == 1, (parts, hits)
+    return by_name[hits[0]]
+
+
+def test_no_kernel_uses_scratch_or_spills(codegen):
+    by_name, _ = codegen
+    assert len(by_name) > 100
+    bad = {k: v for k, v in by_name.items() if v["scratch"] or v["vspill"]}
+    assert not bad, bad
+    # SGPRs parked in VGPR lanes cost nothing in memory; only the exact fp32 kernels at 8 queries per group do it
+    parked = {k for k, v in by_name.items() if v["sspill"]}
+    assert all(k.startswith("scan_exact_kernel<") for k in parked), parked
+
+
+def test_register_budgets_of_the_production_kernels(codegen):
+    by_name, _ = codegen
+    # headline kernel: 8 waves per workgroup, two per SIMD -> 128 VGPRs + 128 AGPRs, no more
+    k = _find(by_name, "filter_f16_m16_kernelILi768ELi4ELb1ELb0ELi0ELi2ELi2ELi8E")
+    assert k["vgpr"] <= 128 and k["agpr"] <= 128 and k["occ"] == 2, k
+    # one-wave-per-SIMD builds: the whole 512-entry file, never beyond
+    for key, v in by_name.items():
+        if "filter_" in key or "filter_" in v["mangled"]:
+            assert v["vgpr"] + v["agpr"] <= 512 and v["occ"] >= 1, (key, v)
+    k = _find(by_name, "filter_i8w_kernel<768, 2, 6, true, 2, false, 0>")
+    assert k["agpr"] >= 192 and k["occ"] == 1, k                      # the hi plane of 64 queries stays resident in AGPRs
+    k = _find(by_name, "filter_f16_kernelILi768ELi1ELi0ELi6E")
+    assert k["agpr"] >= 192, k
+    # refine v3: two workgroups of three waves per CU -> at most 256 registers per lane
+    k = _find(by_name, "refine_l2_rows_kernel<768>")
+    assert k["vgpr"] + k["agpr"] <= 256 and k["occ"] >= 2, k
+
+
+def test_rendezvous_registers_and_hand_placed_instructions(codegen):
+    by_name, asm = codegen
+    n_sync = 0
+    for key, v in by_name.items():
+        body = _body(asm, v["mangled"])
+        if "s_load_dwordx8 s[88:95]" in body:
+            n_sync += 1
+            assert v["sgpr"] >= 96, (key, v)                             # s88..s95 are inside the kernel's allocation
+            # the block's own eight moves are the only readers of s88..s95
+            readers = re.findall(r"^\s*(\S+)\s+[^\n]*\bs(8[89]|9[0-5])\b", body, flags=re.M)
+            assert all(op in ("s_load_dwordx8", "s_mov_b32") for op, _ in readers), (key, set(op for op, _ in readers))
+    assert n_sync >= 8
+    # headline kernel: 192 MFMAs per tile and wave pair -> 96 in the 8-wave build's loop body, fed from AGPRs; the
+    # compiler must not have copied fragments into VGPRs (v_accvgpr_read inside the loop)
+    k = _find(by_name, "filter_f16_m16_kernelILi768ELi4ELb1ELb0ELi0ELi2ELi2ELi8E")
+    body = _body(asm, k["mangled"])
+    assert body.count("v_mfma_f32_16x16x32_f16") >= 96
+    assert body.count("global_load_lds_dwordx4") >= 6 and "s_nop 15" in body
+    loop = body[body.index("s_barrier"):]
+    assert loop.count("v_accvgpr_read") <= 8, loop.count("v_accvgpr_read")
+    # refine v3: q - half as ONE v_fma_mix_f32 per element (hipcc folds the C++ form back into cvt + sub)
+    k = _find(by_name, "refine_l2_rows_kernel<768>")
+    body = _body(asm, k["mangled"])
+    assert body.count("v_fma_mix_f32") == 192 and body.count("v_cvt_f32_f16") == 0 and body.count("global_load_lds_dwordx4") == 24

@@ -534,6 +534,10 @@ def test_refine_matches_restated_reference_order(ctx, oracle, tag, d, R, K):
     assert t.K == K and t.R == R and t.kernel_ms > 0 and abs(t.total_ms - (t.h2d_ms + t.kernel_ms + t.d2h_ms)) < 1e-3
     ids_only, none = ctx.refine_l2_topk(queries, cand, K, want_dist=False)   # CUDA_RETURN_DIST=0
     assert none is None and np.array_equal(ids_only, ids)
+    ctx.set_option("refine_pinned", 1)                                       # CUDA_PINNED=1 (cuda_refine.cu:875, 902-914)
+    pi, pd = ctx.refine_l2_topk(queries, cand, K)
+    ctx.set_option("refine_pinned", 0)
+    assert np.array_equal(pi, ids) and np.array_equal(pd.view(np.uint32), dist.view(np.uint32))
 
 
 def test_refine_argument_conventions(ctx, oracle):
@@ -548,6 +552,32 @@ def test_refine_argument_conventions(ctx, oracle):
     ctx.upload_corpus(b8, po.DT_I8, sc)
     with pytest.raises(nvdb_amd.NvdbError):
         ctx.refine_l2_topk(q, np.zeros((2, 4), dtype=np.uint32), 3)              # int8 base unsupported (nvdb_ivf_eval.cpp:519-525)
+
+
+def test_non_power_of_two_candidate_capacity(ctx, oracle):
+    """cand_cap = 3000 with lists longer than 2048 entries: the bitonic select pads to 4096 entries, its LDS must be
+    sized for that (not for cap).  Near-duplicate rows make the lists long; results stay exact."""
+    n, d, nq, k = 60000, 768, 16, 10
+    rs = np.random.RandomState(17)
+    base32 = nvdb_amd.synth_rows_f32(SEED + 40, 0, n, d)
+    centre = base32[7].copy()
+    dup = rs.choice(n, 2600, replace=False)
+    base32[dup] = centre + rs.standard_normal((2600, d)).astype(np.float32) * np.float32(2e-5)     # 2600 rows inside the filter's error band
+    base = oracle.f32_to_f16(base32)
+    queries = nvdb_amd.synth_rows_f32(SEED + 41, 0, nq, d)
+    queries[0] = centre
+    ctx.upload_corpus(base, po.DT_F16)
+    ctx.set_option("path", 2)
+    ctx.set_option("cand_cap", 3000)
+    ids, sc = ctx.search_batch(queries, k)
+    st = ctx.stats()
+    ctx.set_option("cand_cap", 0)
+    ctx.set_option("path", 0)
+    assert st["bound_violations"] == 0, st
+    oid, osc = oracle.flat_topk(base, po.DT_F16, queries, k)
+    for qi in range(nq):
+        allsc = oracle.scores(base, po.DT_F16, queries[qi], None)
+        assert_topk_equal(ids[qi], sc[qi], oid[qi], osc[qi], score_of=lambda i: allsc[i], what=f"cap3000/q{qi}")
 
 
 # ----------------------------------------------------------------------------- any k (reference: k clamped to N only)

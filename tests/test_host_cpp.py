@@ -154,6 +154,11 @@ def test_gpu_modes_of_the_tools(files, golden):
     assert run("nvdb_search", files["b32"], files["q"], 10, "gpu") == bytes(golden["main768_search_stdout"]).decode()
     run("nvdb_gt_build", files["b16"], files["q"], 10, files["gt"], env={"GT_MODE": "gpu"})
     assert np.array_equal(po.read_gtbin(files["gt"])[0], golden["main768_gtbin_f16_ids"])
+    # k = 100 (> 64, the any-k path): the reference's tool takes any k (apps/nvdb_gt_build.cpp, flat_index.cpp:24)
+    run("nvdb_gt_build", files["b16"], files["q"], 100, files["gt"], env={"GT_MODE": "gpu"})
+    g100 = po.read_gtbin(files["gt"])[0].copy()
+    run("nvdb_gt_build", files["b16"], files["q"], 100, files["gt"], env={"OMP_NUM_THREADS": "3"})        # default mode = omp, as in the reference
+    assert g100.shape == (8, 100) and np.array_equal(g100, po.read_gtbin(files["gt"])[0])
     cpu = run("nvdb_bench", files["b16"], files["q"], 10, "st")
     for extra in ([], ["0", "2", "4"]):
         out = run("nvdb_bench", files["b16"], files["q"], 10, "gpu", *extra)
@@ -166,11 +171,11 @@ def test_gpu_modes_of_the_tools(files, golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtkey", ["b16", "b32"])
-def test_nvdb_cuda_refine_eval(files, dtkey):
-    out = run("nvdb_cuda_refine_eval", files[dtkey], files["q"], 10, env={"REFINE_K": "256"})
+@pytest.mark.parametrize("dtkey,pinned", [("b16", "0"), ("b32", "0"), ("b16", "1")])
+def test_nvdb_cuda_refine_eval(files, dtkey, pinned):
+    out = run("nvdb_cuda_refine_eval", files[dtkey], files["q"], 10, env={"REFINE_K": "256", "CUDA_PINNED": pinned})
     assert out.startswith("CUDA_REFINE=1 refine_ms_total=")
     res = dict(kv.split("=") for kv in out.strip().splitlines()[-1].split()[1:])
     assert res["refine_k"] == "256" and res["Q"] == "8" and res["k"] == "10" and res["refine_backend"] == "cuda"
-    assert float(res["recall_vs_cpu"]) == 1.0
+    assert float(res["recall_vs_cpu"]) == 1.0 and res["cuda_pinned"] == pinned
     assert "identical_rows=8/8" in out

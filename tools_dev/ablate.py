@@ -5,10 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd"))
 import numpy as np, nvdb_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-ctx = nvdb_amd.HipContext(0)
+ctx = nvdb_amd.HipContext(0, dev=True)            # libnvdb_hip_dev.so: the product library has no debug entry points
 ctx.generate_corpus(20240613, n, 768, nvdb_amd.DT_F16)
-lib = nvdb_amd.load_library()
-lib.nvdb_hip_debug_filter_variant.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+lib = ctx.lib
 names = {0: "normal", 1: "no glds", 2: "no glds, no barrier", 3: "no MFMA", 4: "no epilogue", 5: "no LDS reads", 6: "ring 6", 7: "ring 8", 8: "ring 3", 9: "ring 12", 10: "L2-resident corpus (8 tiles/stream), ring 6"}
 variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(names)
 for nq in (1024, 256):

@@ -8,9 +8,9 @@ sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd"))
 import nvdb_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
-ctx = nvdb_amd.HipContext(0)
+ctx = nvdb_amd.HipContext(0, dev=True)            # libnvdb_hip_dev.so
 ctx.generate_corpus(20240613, n, 768, nvdb_amd.DT_F16)
-lib = nvdb_amd.load_library()
+lib = ctx.lib
 for nq in (1024, 512):
     q = nvdb_amd.synth_rows_f32(1, 0, nq, 768)
     ctx.set_option("path", 2); ctx.search_batch(q, 10)

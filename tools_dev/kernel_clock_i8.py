@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""In-kernel clock and MFMA-busy fraction of the int8 two-stage kernel (filter_i8w_kernel<768,2>, batch 1024) and of its
+timing-only ablations: stamped builds (s_memtime / s_memrealtime around the tile loop) launched back to back for a few
+seconds on the synthetic int8 corpus, with the thresholds the preceding search ended with.  Developer tool
+(libnvdb_hip_dev.so); run on the GPU box."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd"))
+import nvdb_amd
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+secs = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
+ctx = nvdb_amd.HipContext(0, dev=True)
+ctx.generate_corpus(20240613, n, 768, nvdb_amd.DT_I8)
+lib = ctx.lib
+nq = 1024
+q = nvdb_amd.synth_rows_f32(20240614, 0, nq, 768)
+ctx.set_option("path", 2); ctx.search_batch(q, 10)
+st = ctx.stats()
+print(f"search: {st}", flush=True)
+names = {0: "production loop", 1: "no stage 2 (lo plane never multiplied)", 2: "no stage-1 test either (stream + hi-plane MFMAs)", 3: "the same without the per-tile barrier"}
+for var in (0, 1, 2, 3, 0, 1):
+    out = (C.c_float * 4)()
+    rc = lib.nvdb_hip_debug_clock_i8(ctx.h, var, nq, secs, out)
+    assert rc == 0, lib.nvdb_hip_last_error(ctx.h)
+    ms, med, lo, hi = out[0], out[1], out[2], out[3]
+    tops = 2.0 * nq * n * 768 / ms / 1e9
+    mfma_cycles = (n / 64) / 64.0 * 96 * 32            # per SIMD: tiles per workgroup x 96 v_mfma_i32_32x32x32_i8 x 32 cycles
+    busy = mfma_cycles / (ms * 1e-3 * med * 1e9)
+    print(f"[{names[var]}] whole-corpus launch {ms:.3f} ms = {tops:.0f} TOP/s algorithmic (hi plane only: half the int8 work of the two-plane kernel); "
+          f"in-kernel clock median {med:.3f} GHz (min {lo:.3f}, max {hi:.3f}); MFMA pipe busy {busy:.3f}; cycles per tile {3072 / busy:.0f}", flush=True)
