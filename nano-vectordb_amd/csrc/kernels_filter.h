@@ -1201,6 +1201,43 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   uint32_t n_stage1 = 0, n_stage2 = 0;             // diagnostics (uniform): tiles of this wave that went past stage 0 / 1
   Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
 
+  // Deferred single value (the common stage-2 case: exactly ONE of the wave's values of a tile passes stage 1).  Instead
+  // of multiplying the whole lo plane of its 32-query block right away -- 24 MFMAs behind an L2 round trip for the
+  // fragments, with the other three waves waiting at the next barrier -- the wave copies that value's corpus row out of
+  // the LDS stage into 4 registers, asks for the query's lo-plane row (768 bytes) by a direct-to-LDS load into its own
+  // 1-KB scratch slot and carries on; one tile later the bytes are there and the exact lo-plane dot product of that one
+  // (row, query) pair is 4 x v_dot4_i32_i8 per lane and a wave reduction.  Same integer, same float expression, same
+  // hit as the block path below.
+  constexpr bool DEFER = (MB == 2) && (NSTAGE * STAGE_BYTES + 4096 <= 160 * 1024) && (DIM % 16 == 0) && (DIM / 16 <= 64);
+  char* scratch = smem + NSTAGE * STAGE_BYTES + wave * 1024;
+  const uint32_t lds_scratch = lds_base + NSTAGE * STAGE_BYTES + wave * 1024;
+  bool pend = false;                               // uniform
+  uint4 pend_x = make_uint4(0, 0, 0, 0);           // lanes < DIM/16: 16 bytes of the pending pair's corpus row
+  int pend_H = 0;
+  float pend_scale = 0.f, pend_thr = 0.f, pend_inv = 0.f;
+  uint32_t pend_qid = 0, pend_row = 0;
+  auto consume_pending = [&](int still_in_flight) {
+    // the scratch load is older than the newest `still_in_flight` loads of this wave
+    if (still_in_flight == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
+    int part = 0;
+    if (lane < DIM / 16) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(scratch + lane * 16);
+      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.x), static_cast<int>(lo.x), part, false);
+      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.y), static_cast<int>(lo.y), part, false);
+      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.z), static_cast<int>(lo.z), part, false);
+      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.w), static_cast<int>(lo.w), part, false);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);          // exact: integer sum
+    const float fv = static_cast<float>(pend_H * 128 + part) * pend_scale;
+    if (fv >= pend_thr) {
+      if (lane == 0 && wcnt < FILTER_LOGCAP) mylog[wcnt] = Hit{fv * pend_inv, pend_row, pend_qid, 0u};
+      ++wcnt;
+    }
+    pend = false;
+  };
+
   uint32_t sync_strikes = 0;
   uint64_t stamp_c = 0, stamp_r = 0;
   if constexpr (STAMP) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
@@ -1276,10 +1313,43 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
         d1[mb][nb] = vmax3(m, fh[15], fh[15]) - t1q[nb];                 // >= 0 iff some value reaches the threshold
         dall = vmax3(dall, d1[mb][nb], d1[mb][nb]);
       }
+    if constexpr (DEFER) { if (pend) consume_pending(1); }             // issued one tile ago: PPW + 1 younger loads in flight
     if (!__builtin_amdgcn_ballot_w64(dall >= 0.f)) continue;
     ++n_stage1;
     if constexpr (VAR == 1) continue;
     const uint32_t row0 = tile_row0(t);
+    if constexpr (DEFER) {
+      // rare path: which values pass?  (the same comparison as the max tree, value by value)
+      uint32_t nflag = 0;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          if (!__builtin_amdgcn_ballot_w64(d1[mb][nb] >= 0.f)) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(static_cast<float>(acc[mb][nb][r]) * scv[mb][r] >= t1q[nb]);
+            if (m) {
+              nflag += static_cast<uint32_t>(__builtin_popcountll(m));
+              const int L = __builtin_ctzll(m);
+              pend_H = __builtin_amdgcn_readlane(acc[mb][nb][r], L);
+              pend_scale = readlane_f(scv[mb][r], L);
+              pend_thr = readlane_f(thr_s[nb], L);
+              pend_inv = readlane_f(inv_s[nb], L);
+              pend_qid = readlane_u(qid[nb], L);
+              pend_row = 32u * mb + (r & 3) + 8u * (r >> 2) + 4u * (static_cast<uint32_t>(L) >> 5);      // row inside the tile
+            }
+          }
+        }
+      if (nflag == 1) {
+        // its corpus row: chunk l of row i sits at position l ^ (i & 15) of the stage's row image
+        if (lane < DIM / 16) pend_x = *reinterpret_cast<const uint4*>(stage + pend_row * ROW_BYTES + ((static_cast<uint32_t>(lane) ^ (pend_row & 15u)) << 4));
+        if (lane < DIM / 16) glds16(static_cast<uint32_t>(lane) * 16u, qlo + static_cast<uint64_t>(pend_qid) * DIM, lds_scratch);
+        pend_row += row0;
+        pend = true;
+        continue;
+      }
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -1318,6 +1388,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
         }
       }
   }
+  if constexpr (DEFER) { if (pend) consume_pending(0); }
   if constexpr (STAMP) {
     const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c, dr = __builtin_amdgcn_s_memrealtime() - stamp_r;
     if (wave == 0 && lane == 0) {

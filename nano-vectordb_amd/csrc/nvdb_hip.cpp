@@ -571,7 +571,7 @@ nvdb_status launch_boot_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_
 template <int DIM, int NB>
 nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
                                   uint32_t nq_pad, uint32_t cap) {
-  constexpr size_t lds = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + 4 * 1024);       // 64-row tiles, three stages
+  constexpr size_t lds = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + 4 * 1024) + 4096;   // 64-row tiles, three stages + 1 KB of lo-plane scratch per wave
   uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
   if (nwg == 0) nwg = QT;
   nvdb_status st;
@@ -1473,7 +1473,7 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
   nvdb_status st;
   if ((st = ensure(c, c->prog, std::max(prog_bytes + stamp_bytes, static_cast<size_t>(PROG_SLOTS) * c->num_cu * 8 * 4)))) return st;
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
-  constexpr size_t lds = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + 4 * 1024);
+  constexpr size_t lds = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + 4 * 1024) + 4096;
   const uint32_t n_al = static_cast<uint32_t>(c->n / I8W_TILE_ROWS * I8W_TILE_ROWS);
   const signed char* qhi = static_cast<const signed char*>(c->q16.p);
   const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * 768;
