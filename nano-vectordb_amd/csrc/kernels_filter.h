@@ -1402,6 +1402,329 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// int8 two-stage build, software-pipelined (batches > 128: NB = 2 query blocks per wave, 64-row tiles).
+//
+// filter_i8w_kernel spends ~950 of its ~5200 cycles per tile in the stage-1 test AFTER the tile's MFMAs
+// (profiles/r02_i8_clock_ablation.txt: 64 cvt + 64 mul + a max tree per wave and tile, nothing else running on the SIMD).
+// Here the two 32-row blocks of a tile are multiplied one after the other and each block's test runs in the shadow of
+// the OTHER block's MFMAs -- an MFMA holds the SIMD's issue port for 8 of its 32 cycles, the rest takes VALU work:
+//
+//   tile t:  barrier A | MFMAs(block 0, tile t)  ||  test(block 1, tile t-1), its rare path | barrier B |
+//                        MFMAs(block 1, tile t)  ||  loads of tile t+2, test(block 0, tile t), its rare path
+//
+// No second accumulator set: block 0's accumulators are tested while block 1's are written and vice versa.  Barrier B
+// is what the overlap costs: block 1 of tile t-1 is tested during tile t, and its rare path still reads that tile's LDS
+// stage, so the loads that overwrite it (tile t+2, same buffer) are issued only after every wave has passed B.
+// The rare path is filter_i8w_kernel's: one flagged value -> deferred exact dot product (v_dot4), several -> lo-plane
+// MFMAs of the block.  Same survivors, same filter scores (test_int8_two_stage_kernel_matches_two_plane_kernel).
+// ------------------------------------------------------------------------------------------------
+template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6>
+__global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
+    const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
+    const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
+    const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qinv,
+    const float* __restrict__ qdelta, Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t* __restrict__ prog,
+    uint32_t sync_mask, uint32_t sync_lead, uint32_t* __restrict__ stage_counts) {
+  constexpr int NB = 2, MB = 2;
+  constexpr int KSTEPS = DIM / 32;
+  constexpr int ROW_BYTES = DIM;
+  constexpr int TROWS = FILTER_ROWS * MB;
+  constexpr int NSTAGE = 3;
+  constexpr int DATA_BYTES = TROWS * ROW_BYTES;
+  constexpr int STAGE_BYTES = DATA_BYTES + 4 * 1024;
+  constexpr int PIECES = DATA_BYTES / 1024;
+  constexpr int PPW = PIECES / 4;
+  constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
+  static_assert(DIM % 256 == 0 && DIM <= 768, "row stride multiple of 256 bytes; int32 range of 128*H + L");
+  static_assert(PIECES % 4 == 0 && KSTEPS % PPW == 0 && KSTEPS % 2 == 0 && KSTEPS >= 8, "shape");
+  static_assert(NSTAGE * STAGE_BYTES + 4096 <= 160 * 1024 && PPW + 1 < 64, "LDS / vmcnt range");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, hsel = lane >> 5;
+  const uint32_t wave_gid = blockIdx.x * 4 + wave;
+
+  const uint32_t nwg = gridDim.x, b = blockIdx.x;
+  const uint32_t S = nwg / QT;
+  uint32_t stream, qt;
+  if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
+  else { qt = b % QT; stream = b / QT; }
+  const uint32_t tiles_total = (row_hi - row_lo) / TROWS;
+  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
+  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const uint32_t NT = t_hi - t_lo;
+  if (NT == 0) return;
+
+  // stationary operand: hi plane of this wave's 2 blocks of 32 queries, all of K, in AGPRs
+  const uint32_t qbase = qt * (128u * NB) + wave * (32u * NB);
+  float4_t bq[NB * KSTEPS];
+#pragma unroll
+  for (int f = 0; f < NB * KSTEPS; ++f) {
+    const int nb = f / KSTEPS, s = f % KSTEPS;
+    bq[f] = *reinterpret_cast<const float4_t*>(qhi + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 32 * s + 16 * hsel);
+  }
+#pragma unroll
+  for (int f = 0; f < NB * KSTEPS; ++f) asm volatile("" ::"a"(bq[f]));
+  uint32_t qid[NB];
+  float thr_s[NB], t1q[NB], inv_s[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    qid[nb] = qbase + nb * 32 + r31;
+    const bool real = qid[nb] < nq;
+    thr_s[nb] = real ? thr[qid[nb]] * qscale[qid[nb]] : __builtin_huge_valf();
+    inv_s[nb] = real ? qinv[qid[nb]] : 0.f;
+    const float T = thr_s[nb];
+    t1q[nb] = real ? (T - (1.001f * qdelta[qid[nb]] + 2e-6f * fabsf(T) + 1e-5f)) * 0.0078125f : __builtin_huge_valf();   // as filter_i8w_kernel
+    asm volatile("" ::"v"(thr_s[nb]), "v"(inv_s[nb]), "v"(t1q[nb]));
+  }
+  const bool wave_has_queries = qbase < nq;
+
+  uint32_t src_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const uint32_t P = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
+    const uint32_t r = P / CHUNKS_PER_ROW, cpos = P % CHUNKS_PER_ROW;
+    src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
+  }
+  const uint32_t sc_off = (lane & (8 * MB - 1)) * 16;
+  const uint32_t a_base = r31 * ROW_BYTES + ((static_cast<uint32_t>(hsel) ^ (r31 & 15u)) << 4);
+
+  const char* gbase = reinterpret_cast<const char*>(rows);
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
+  const uint32_t g_lo = row_lo / TROWS + t_lo;
+  auto tile_row0 = [&](uint32_t t_rel) -> uint32_t { return perm_tile(g_lo + (t_rel < NT ? t_rel : NT - 1), sa) * TROWS; };
+  auto issue_piece = [&](uint32_t row0, uint32_t buf, int i) {
+    glds16(src_off[i], gbase + static_cast<uint64_t>(row0) * ROW_BYTES, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
+  };
+  auto issue_scales = [&](uint32_t row0, uint32_t buf) {
+    if (lane < 8 * MB) glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 1024);
+  };
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(tile_row0(st), st, i);
+    issue_scales(tile_row0(st), st);
+  }
+
+  uint32_t wcnt = 0;
+  uint32_t n_stage1 = 0, n_stage2 = 0;
+  Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
+
+  // deferred single value (see filter_i8w_kernel): corpus row in 4 registers, the query's lo-plane row on its way into
+  // this wave's 1-KB LDS scratch; consumed at the end of a tile's second half, 13 younger loads behind it
+  char* scratch = smem + NSTAGE * STAGE_BYTES + wave * 1024;
+  const uint32_t lds_scratch = lds_base + NSTAGE * STAGE_BYTES + wave * 1024;
+  bool pend = false;
+  uint4 pend_x = make_uint4(0, 0, 0, 0);
+  int pend_H = 0;
+  float pend_scale = 0.f, pend_thr = 0.f, pend_inv = 0.f;
+  uint32_t pend_qid = 0, pend_row = 0;
+  auto consume_pending = [&](bool drain) {
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
+    int part = 0;
+    if (lane < DIM / 16) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(scratch + lane * 16);
+      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.x), static_cast<int>(lo.x), part, false);
+      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.y), static_cast<int>(lo.y), part, false);
+      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.z), static_cast<int>(lo.z), part, false);
+      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.w), static_cast<int>(lo.w), part, false);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const float fv = static_cast<float>(pend_H * 128 + part) * pend_scale;
+    if (fv >= pend_thr) {
+      if (lane == 0 && wcnt < FILTER_LOGCAP) mylog[wcnt] = Hit{fv * pend_inv, pend_row, pend_qid, 0u};
+      ++wcnt;
+    }
+    pend = false;
+  };
+
+  intx16 acc0[NB], acc1[NB];                       // row block 0 / 1 of the tile in flight
+  float scv[16];                                   // row scales of the block under test
+  float mx[NB];                                    // running max of H * scale per query block
+  float4_t ar[RING];
+
+  // one 32-row block's MFMAs (KSTEPS k-steps x NB query blocks) with `slot(s)` called after every k-step
+  auto read_a = [&](const char* stage, int s, int mb) -> float4_t {
+    return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256 + mb * FILTER_ROWS * ROW_BYTES);
+  };
+  auto load_scales = [&](const char* stage, int mb) {
+    const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(sc_lds + 32 * mb + 8 * j + 4 * hsel);
+      scv[4 * j] = v.x; scv[4 * j + 1] = v.y; scv[4 * j + 2] = v.z; scv[4 * j + 3] = v.w;
+    }
+  };
+  // value v (0..31) of a block's stage-1 test: query block v / 16, accumulator register v % 16 -- cvt + mul, and a
+  // v_max3 every second value: at most 3 VALU instructions behind one MFMA, inside its 24 free issue cycles
+  float fprev = 0.f;
+  auto test_value = [&](const intx16 (&a)[NB], int v) {
+    const int nb = v / 16, r = v % 16;
+    const float f = static_cast<float>(a[nb][r]) * scv[r];
+    if (r & 1) mx[nb] = vmax3(mx[nb], fprev, f); else fprev = f;
+  };
+  // rare path of one tested block: `a` its accumulators, `stage` / `row0` its tile, mb its row block
+  auto rare_path = [&](const intx16 (&a)[NB], const char* stage, uint32_t row0, int mb) {
+    ++n_stage1;
+    uint32_t nflag = 0;
+    int c_H = 0;
+    float c_scale = 0.f, c_thr = 0.f, c_inv = 0.f;
+    uint32_t c_qid = 0, c_row = 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (!__builtin_amdgcn_ballot_w64(mx[nb] >= t1q[nb])) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(static_cast<float>(a[nb][r]) * scv[r] >= t1q[nb]);
+        if (m) {
+          nflag += static_cast<uint32_t>(__builtin_popcountll(m));
+          const int L = __builtin_ctzll(m);
+          c_H = __builtin_amdgcn_readlane(a[nb][r], L);
+          c_scale = readlane_f(scv[r], L);
+          c_thr = readlane_f(thr_s[nb], L);
+          c_inv = readlane_f(inv_s[nb], L);
+          c_qid = readlane_u(qid[nb], L);
+          c_row = 32u * mb + (r & 3) + 8u * (r >> 2) + 4u * (static_cast<uint32_t>(L) >> 5);
+        }
+      }
+    }
+    if (nflag == 1 && !pend) {                     // the scratch slot is free: defer this one value
+      pend_H = c_H; pend_scale = c_scale; pend_thr = c_thr; pend_inv = c_inv; pend_qid = c_qid;
+      if (lane < DIM / 16) pend_x = *reinterpret_cast<const uint4*>(stage + c_row * ROW_BYTES + ((static_cast<uint32_t>(lane) ^ (c_row & 15u)) << 4));
+      if (lane < DIM / 16) glds16(static_cast<uint32_t>(lane) * 16u, qlo + static_cast<uint64_t>(c_qid) * DIM, lds_scratch);
+      pend_row = c_row + row0;
+      pend = true;
+      return;
+    }
+    if (nflag == 0) return;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (!__builtin_amdgcn_ballot_w64(mx[nb] >= t1q[nb])) continue;
+      ++n_stage2;
+      const signed char* ql = qlo + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 16 * hsel;
+      intx16 lo;
+      constexpr int HALF = KSTEPS / 2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4_t bl[HALF];
+#pragma unroll
+        for (int s = 0; s < HALF; ++s) bl[s] = *reinterpret_cast<const float4_t*>(ql + 32 * (h * HALF + s));
+#pragma unroll
+        for (int s = 0; s < HALF; ++s) {
+          const float4_t av = read_a(stage, h * HALF + s, mb);
+          if (h == 0 && s == 0) NVDB_MFMA_I8_ZERO_V(lo, av, bl[s]); else NVDB_MFMA_I8_ACC_V(lo, av, bl[s]);
+        }
+      }
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(lo));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float fv = static_cast<float>(a[nb][r] * 128 + lo[r]) * scv[r];
+        const bool hit = fv >= thr_s[nb];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (m) {
+          const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+          if (hit && idx < FILTER_LOGCAP) mylog[idx] = Hit{fv * inv_s[nb], row0 + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * hsel, qid[nb], 0u};
+          wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
+        }
+      }
+    }
+  };
+
+  uint32_t sync_strikes = 0;
+  uint64_t stamp_c = 0, stamp_r = 0;
+  if constexpr (STAMP) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
+  for (uint32_t t = 0; t < NT; ++t) {
+    if constexpr (SYNC) {
+      if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(prog + static_cast<uint64_t>(stream) * 8, qt, t, sync_lead, sync_strikes, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");         // tile t has landed (tile t+1 may still be in flight)
+    __builtin_amdgcn_s_barrier();                                          // A
+    const uint32_t next_row0 = tile_row0(t + 2), next_buf = (t + 2) % NSTAGE;
+    const char* stage = smem + (t % NSTAGE) * STAGE_BYTES;
+    const char* prev_stage = smem + ((t + NSTAGE - 1) % NSTAGE) * STAGE_BYTES;
+    if (!wave_has_queries) {
+      __builtin_amdgcn_s_barrier();                                        // B
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) issue_piece(next_row0, next_buf, i);
+      issue_scales(next_row0, next_buf);
+      continue;
+    }
+    // Behind every MFMA at most one value of the other block's test (slots W0 .. W0 + 31 of the half's 2 KSTEPS MFMAs:
+    // <= 3 VALU instructions inside the MFMA's 24 free issue cycles).  The A-fragment ring is primed per half: keeping it
+    // alive across the rare path between the halves costs more registers than the file has.
+    constexpr int NSLOT = 2 * KSTEPS, W0 = NSLOT / 4 < 8 ? NSLOT / 4 : 8, VPS = (32 + NSLOT - W0 - 1) / (NSLOT - W0);   // values per slot: 1 at d = 768
+    // ---- first half: block 0 of tile t  ||  test of block 1 of tile t-1 (t == 0: garbage, tested and ignored) ----------
+    load_scales(prev_stage, 1);
+    mx[0] = mx[1] = -__builtin_huge_valf();
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(stage, s, 0);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(stage, s + RING - 1, 0);
+      const float4_t av = ar[s % RING];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if (s == 0) NVDB_MFMA_I8_ZERO(acc0[nb], av, bq[nb * KSTEPS]);
+        else NVDB_MFMA_I8_ACC(acc0[nb], av, bq[nb * KSTEPS + s]);
+        const int w = 2 * s + nb;
+#pragma unroll
+        for (int v = (w - W0) * VPS; v < (w - W0 + 1) * VPS; ++v) if (w >= W0 && v < 32) test_value(acc1, v);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (t > 0 && __builtin_amdgcn_ballot_w64(mx[0] >= t1q[0] || mx[1] >= t1q[1])) rare_path(acc1, prev_stage, tile_row0(t - 1), 1);
+    __builtin_amdgcn_s_barrier();                                          // B: nobody reads the stage of tile t-1 any more
+    // ---- second half: block 1 of tile t  ||  loads of tile t+2, test of block 0 of tile t ---------------------------
+    load_scales(stage, 0);
+    mx[0] = mx[1] = -__builtin_huge_valf();
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(stage, s, 1);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(stage, s + RING - 1, 1);
+      const float4_t av = ar[s % RING];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if (s == 0) NVDB_MFMA_I8_ZERO(acc1[nb], av, bq[nb * KSTEPS]);
+        else NVDB_MFMA_I8_ACC(acc1[nb], av, bq[nb * KSTEPS + s]);
+        const int w = 2 * s + nb;
+#pragma unroll
+        for (int v = (w - W0) * VPS; v < (w - W0 + 1) * VPS; ++v) if (w >= W0 && v < 32) test_value(acc0, v);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (s % (KSTEPS / PPW) == KSTEPS / PPW - 1) issue_piece(next_row0, next_buf, s / (KSTEPS / PPW));
+      if (s == 0) issue_scales(next_row0, next_buf);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (pend) consume_pending(false);                                      // PPW + 1 younger loads behind it: this tile's
+    if (__builtin_amdgcn_ballot_w64(mx[0] >= t1q[0] || mx[1] >= t1q[1])) rare_path(acc0, stage, tile_row0(t), 0);
+  }
+  if (wave_has_queries) {                          // block 1 of the last tile
+    const char* last_stage = smem + ((NT - 1) % NSTAGE) * STAGE_BYTES;
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    load_scales(last_stage, 1);
+    mx[0] = mx[1] = -__builtin_huge_valf();
+#pragma unroll
+    for (int v = 0; v < 32; ++v) test_value(acc1, v);
+    if (pend) consume_pending(true);
+    if (__builtin_amdgcn_ballot_w64(mx[0] >= t1q[0] || mx[1] >= t1q[1])) rare_path(acc1, last_stage, tile_row0(NT - 1), 1);
+    if (pend) consume_pending(true);
+  }
+  if constexpr (STAMP) {
+    const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c, dr = __builtin_amdgcn_s_memrealtime() - stamp_r;
+    if (wave == 0 && lane == 0) {
+      uint64_t* out = reinterpret_cast<uint64_t*>(prog + static_cast<uint64_t>(gridDim.x) * 8) + static_cast<uint64_t>(blockIdx.x) * 2;
+      out[0] = dc; out[1] = dr;
+    }
+  }
+  if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(prog + static_cast<uint64_t>(stream) * 8 + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (stage_counts && lane == 0 && (n_stage1 | n_stage2)) { atomicAdd(stage_counts, n_stage1); atomicAdd(stage_counts + 1, n_stage2); }
+  scatter_own_log(mylog, wcnt, sa, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // synthetic corpus generator: one wave per row (bit-identical to nvdb_synth_rows_f32 on the host
 // followed by the RNE half conversion / the reference's int8 quantiser).
 // ------------------------------------------------------------------------------------------------

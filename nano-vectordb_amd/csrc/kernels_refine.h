@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void refine_l2_lds_kernel(const void* __res
 namespace nvdbhip {
 
 // ------------------------------------------------------------------------------------------------
-// refine, version 3 (fp16 rows, dim in {256, 512, 768}): WHOLE rows per request, four lanes per row.
+// refine, version 3 (fp16 rows, dim in {256, 384, 512, 768}): WHOLE rows per request, four lanes per row.
 //
 // v2 above fetches a row as six 256-byte pieces that are microseconds apart: every piece re-opens the row's DRAM page,
 // and the gather saturated at 4.3 TB/s with FETCH_SIZE == algorithmic bytes (profiles/r02_refine_v2_*.txt) -- the
@@ -279,8 +279,8 @@ namespace nvdbhip {
 //     it reads pair 4i + c of every 16-byte piece i with ds_read2_b32 at STATIC offsets and keeps its own 2 x dim/8
 //     query elements in registers for the whole query.  dx = q - float(x) is ONE v_fma_mix_f32 (x read as the low /
 //     high half of the packed register, times -1.0, plus q: a single rounding, the same bits as the subtraction).
-//   * LDS image: row r's first KB at r * 1040 (16 bytes of padding: the 8 rows of a half-wave hit 8 x 4 distinct
-//     banks), remainders of rows j and j + 8 in one KB at j * 1040 (the two rows are read by different half-waves).
+//   * LDS image: row r's first KB (or the whole shorter row) in a block padded by 16 bytes (the 8 rows of a half-wave hit
+//     8 x 4 distinct banks), remainders of rows j and j + 8 in one KB at j * 1040 (read by different half-waves).
 //   * d = (a0 + a1) + (a2 + a3) by two quad shuffles, then the same wavefront-resident top-K as v1/v2.
 // Results are bit-identical to v1/v2 and to the oracle's restatement (tests + tools_dev/fuzz_refine.py).
 // ------------------------------------------------------------------------------------------------
@@ -308,10 +308,14 @@ __device__ __forceinline__ float q_minus_half_hi(uint32_t xpk, float q) {
   return r;
 }
 
-constexpr int REFINE3_WAVES = 3, REFINE3_ROWS = 16, REFINE3_BLOCK = 1040;
+constexpr int REFINE3_WAVES = 3, REFINE3_ROWS = 16;
+// LDS image of a wave's 16 rows: piece A = the row's first min(row, 1 KB) bytes (LA lanes x 16 B) in a block of
+// LA * 16 + 16 bytes (the 16 bytes of padding put the 8 rows of a half-wave on 8 x 4 distinct banks), then -- for 1536-byte
+// rows -- the 512-byte remainders of rows j and j + 8 share one 1040-byte block.
+template <int DIM> constexpr int refine3_la() { return DIM * 2 >= 1024 ? 64 : DIM * 2 / 16; }
 template <int DIM> constexpr int refine3_slot_bytes() {
-  constexpr int RB = DIM * 2, NA = RB / 1024, HAS_B = (RB % 1024) ? 1 : 0;
-  return REFINE3_ROWS * NA * REFINE3_BLOCK + HAS_B * (REFINE3_ROWS / 2) * REFINE3_BLOCK;
+  constexpr int RB = DIM * 2, LA = refine3_la<DIM>(), REM = RB - LA * 16;
+  return REFINE3_ROWS * (LA * 16 + 16) + (REM ? (REFINE3_ROWS / 2) * 1040 : 0);
 }
 
 template <int DIM>
@@ -319,13 +323,13 @@ __global__ __launch_bounds__(64 * REFINE3_WAVES) void refine_l2_rows_kernel(cons
                                                                             const uint32_t* __restrict__ cand, uint32_t R, uint32_t K,
                                                                             uint32_t* __restrict__ out_ids, float* __restrict__ out_dist) {
   constexpr int RB = DIM * 2;                       // row bytes
-  constexpr int NA = RB / 1024;                     // whole 1-KB pieces per row
-  constexpr int REM = RB % 1024;                    // 0 or 512: remainder, two rows per piece
-  static_assert(REM == 0 || REM == 512, "row bytes must be a multiple of 512");
-  static_assert(NA <= 1, "rows longer than 1536 bytes take the v2 kernel");
+  constexpr int LA = refine3_la<DIM>();             // lanes of piece A (16 bytes each): the whole row up to 1 KB
+  constexpr int REM = RB - LA * 16;                 // 0, or 512 for 1536-byte rows: remainder, two rows per piece
+  static_assert(DIM % 8 == 0 && (REM == 0 || REM == 512), "rows of up to 1 KB, or of 1536 bytes");
   constexpr int NPAIR = DIM / 8;                    // pairs per lane = 16-byte pieces per row
   constexpr int SLOT = refine3_slot_bytes<DIM>();
-  constexpr int BOFF = REFINE3_ROWS * NA * REFINE3_BLOCK;
+  constexpr int ABLOCK = LA * 16 + 16, BBLOCK = 1040;
+  constexpr int BOFF = REFINE3_ROWS * ABLOCK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float lds_d[REFINE3_WAVES][64];
   __shared__ uint32_t lds_id[REFINE3_WAVES][64];
@@ -350,9 +354,9 @@ __global__ __launch_bounds__(64 * REFINE3_WAVES) void refine_l2_rows_kernel(cons
   tk.d = 1e30f; tk.id = 0xFFFFFFFFu; tk.cnt = 0; tk.thr_d = 1e30f; tk.thr_id = 0xFFFFFFFFu;
 
   const uint32_t voffA = static_cast<uint32_t>(lane) * 16u;                                 // piece A: lane l <- bytes [16 l, 16 l + 16) of the row
-  const uint32_t lane_lo = static_cast<uint32_t>(lane & 31) * 16u + NA * 1024u;             // piece B: 32 lanes per row, after the A part
-  const char* rdA = myslot + r * REFINE3_BLOCK + c * 4;                                     // this lane's read bases
-  const char* rdB = myslot + BOFF + (r & 7) * REFINE3_BLOCK + (r >> 3) * 512 + c * 4;
+  const uint32_t lane_lo = static_cast<uint32_t>(lane & 31) * 16u + LA * 16u;               // piece B: 32 lanes per row, after the A part
+  const char* rdA = myslot + r * ABLOCK + c * 4;                                            // this lane's read bases
+  const char* rdB = myslot + BOFF + (r & 7) * BBLOCK + (r >> 3) * 512 + c * 4;
 
   uint32_t idx = wave * REFINE3_ROWS + (lane & 15);
   uint32_t ids_next = (idx < R) ? cq[idx] : 0xFFFFFFFFu;
@@ -368,13 +372,13 @@ __global__ __launch_bounds__(64 * REFINE3_WAVES) void refine_l2_rows_kernel(cons
       const bool ok1 = (sid1 != 0xFFFFFFFFu) && (static_cast<uint64_t>(sid1) < n);
       const uint64_t off0 = static_cast<uint64_t>(ok0 ? sid0 : 0u) * RB;                   // skipped candidates: row 0, dropped below
       const uint64_t off1 = static_cast<uint64_t>(ok1 ? sid1 : 0u) * RB;
-      if constexpr (NA == 1) {                       // wave-uniform branches
-        if (ok0) glds16_imm<0>(voffA, gbase + off0, lds_mine + j * REFINE3_BLOCK);
-        if (ok1) glds16_imm<0>(voffA, gbase + off1, lds_mine + (j + 8) * REFINE3_BLOCK);
+      if (lane < LA) {                               // (all 64 lanes for rows of 1 KB and more); ok0 / ok1: wave-uniform branches
+        if (ok0) glds16_imm<0>(voffA, gbase + off0, lds_mine + j * ABLOCK);
+        if (ok1) glds16_imm<0>(voffA, gbase + off1, lds_mine + (j + 8) * ABLOCK);
       }
       if constexpr (REM != 0) {
         const uint64_t o = (lane < 32 ? off0 : off1) + lane_lo;                            // the two rows are read by different half-waves
-        if (ok0 || ok1) glds16_v(gbase + o, lds_mine + BOFF + j * REFINE3_BLOCK);
+        if (ok0 || ok1) glds16_v(gbase + o, lds_mine + BOFF + j * BBLOCK);
       }
     }
     const uint32_t my_id = static_cast<uint32_t>(__shfl(static_cast<int>(ids), r));
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(64 * REFINE3_WAVES) void refine_l2_rows_kernel(cons
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < NPAIR; ++i) {
-      const char* src = (i < NA * 64) ? rdA + i * 16 : rdB + (i - NA * 64) * 16;
+      const char* src = (i < LA) ? rdA + i * 16 : rdB + (i - LA) * 16;
       const uint32_t x = *reinterpret_cast<const uint32_t*>(src);                          // half2 pair (x[2p], x[2p+1])
       const float dx = q_minus_half_lo(x, qv[i].x);
       const float dy = q_minus_half_hi(x, qv[i].y);

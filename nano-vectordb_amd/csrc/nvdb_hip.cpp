@@ -68,6 +68,7 @@ struct nvdb_hip_ctx {
   uint32_t fdim = 0;                               // dim the filter kernels run at (>= dim; == dim without padding)
   DevBuf qdelta;                                   // int8: per query, what the lo plane can add to a filter value
   int64_t opt_i8_wide = 1;
+  int64_t opt_i8_pipe = 1;                         // int8 batches > 128: software-pipelined build (stage-1 test in the shadow of the other row block's MFMAs)
   int64_t opt_waves8 = 1;                          // d=768: 8-wave workgroups (two waves per SIMD, 32 queries each) for the fp16 m16 kernel: +2.3 % (0: four waves x 64 queries)
   void* pinned = nullptr;                           // pinned host staging of small calls: status words, results, queries
   size_t pinned_bytes = 0;
@@ -106,7 +107,7 @@ struct nvdb_hip_ctx {
   int64_t opt_sibling_sync = 1;                    // 1: co-streaming workgroups rendezvous every 8 tiles (L2 sharing)
   int64_t opt_f32_shadow = 1;                      // 1: fp32 corpora get an fp16 shadow copy for the MFMA filter
   int64_t opt_mfma_boot = 1;                       // 1: threshold bootstrap on the matrix cores (fp16 corpora)
-  int64_t opt_refine_v2 = 2;                       // refine kernel: 0 lane per row, 1 column chunks through LDS, 2 whole rows through LDS (fp16 d = 256/512/768; else 1)
+  int64_t opt_refine_v2 = 2;                       // refine kernel: 0 lane per row, 1 column chunks through LDS, 2 whole rows through LDS (fp16 d = 256/384/512/768; else 1)
   int64_t opt_mfma16 = 1;                          // 1: use the 16x16x32 MFMA build for 256-query tiles
   std::set<const void*> lds_attr_set;              // kernels whose dynamic-LDS limit was raised on this device
 };
@@ -170,6 +171,7 @@ constexpr uint32_t F16_FILTER_MAX_DIM = 3072;
 constexpr uint32_t I8W_TILE_ROWS = 64;                // rows per tile of the int8 two-stage kernel (two 32-row blocks)
 constexpr uint32_t PAD_ROWS = 64;                     // zero rows every library-owned corpus / shadow is padded with: the largest tile
 bool i8_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 256; }   // int8 rows: stride % 256 == 0
+bool refine3_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256; }   // fp16 dims of the whole-row refine kernel
 
 nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   nvdb_status st = ensure(c, c->misc, 64);
@@ -592,14 +594,29 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
   }
+#define NVDB_I8P_LAUNCH(SYNCV, PROG, MASK, LEAD)                                                                                  \
+  {                                                                                                                             \
+    const void* fn = reinterpret_cast<const void*>(filter_i8p_kernel<DIM, SYNCV>);                                              \
+    if (!c->lds_attr_set.count(fn)) {                                                                                           \
+      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
+      c->lds_attr_set.insert(fn);                                                                                               \
+    }                                                                                                                           \
+    hipExtLaunchKernelGGL((filter_i8p_kernel<DIM, SYNCV>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
+        static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
+        static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
+  }
+  const bool pipe = (NB == 2) && c->opt_i8_pipe;
   if (sync) {
     uint32_t* prog = nullptr;
     if ((st = next_prog_region(c, s, nwg, &prog))) return st;
-    NVDB_I8W_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead))
+    if (pipe) NVDB_I8P_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead))
+    else NVDB_I8W_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead))
   } else {
-    NVDB_I8W_LAUNCH(false, nullptr, 0u, 0u)
+    if (pipe) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u)
+    else NVDB_I8W_LAUNCH(false, nullptr, 0u, 0u)
   }
 #undef NVDB_I8W_LAUNCH
+#undef NVDB_I8P_LAUNCH
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -1065,6 +1082,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "sibling_sync") { c->opt_sibling_sync = value ? 1 : 0; }
   else if (k == "f32_shadow") { c->opt_f32_shadow = value ? 1 : 0; }
   else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }
+  else if (k == "i8_pipe") { c->opt_i8_pipe = value ? 1 : 0; }
   else if (k == "waves8") { c->opt_waves8 = value ? 1 : 0; }
   else if (k == "tile_permute") { c->opt_tile_permute = value ? 1 : 0; }
   else if (k == "rescore8") { c->opt_rescore8 = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -1503,6 +1521,17 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
       case 1: NVDB_CLK_I8(1) break;
       case 2: NVDB_CLK_I8(2) break;
       case 3: NVDB_CLK_I8(3) break;
+      case 10: {                                  // the software-pipelined production build, stamped
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_i8p_kernel<768, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        for (uint32_t r = 0; r < burst; ++r) {
+          HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, prog_bytes, c->stream));
+          filter_i8p_kernel<768, true, true><<<nwg, 256, lds, c->stream>>>(
+              filter_rows_i8(c), filter_scales_i8(c), 0, n_al, qhi, qlo, nq, QT, static_cast<const float*>(c->thr.p),
+              static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<const float*>(c->qdelta.p),
+              static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap, I8W_TILE_ROWS), static_cast<uint32_t*>(c->prog.p),
+              static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), nullptr);
+        }
+      } break;
       default: return fail(c, NVDB_ERR_INVALID, "debug: unknown variant");
     }
     HIPCHK(c, hipGetLastError());
@@ -1605,7 +1634,7 @@ static nvdb_status launch_refine(nvdb_hip_ctx* c, hipStream_t s, const float* dq
                                  uint32_t K, uint32_t* doi, float* dod) {
   const bool al = aligned_rows(c->dtype, c->dim);
   // v3 (whole rows per request, four lanes per row): fp16 rows of 512 / 1024 / 1536 bytes
-  if (c->opt_refine_v2 >= 2 && c->dtype == NVDB_DTYPE_F16 && (c->dim == 768 || c->dim == 512 || c->dim == 256)) {
+  if (c->opt_refine_v2 >= 2 && c->dtype == NVDB_DTYPE_F16 && refine3_dim(c->dim)) {
 #define NVDB_REFINE3(D)                                                                                                        \
     {                                                                                                                          \
       constexpr size_t lds = static_cast<size_t>(REFINE3_WAVES) * refine3_slot_bytes<D>();                                      \
@@ -1616,7 +1645,7 @@ static nvdb_status launch_refine(nvdb_hip_ctx* c, hipStream_t s, const float* dq
       }                                                                                                                        \
       refine_l2_rows_kernel<D><<<Q, 64 * REFINE3_WAVES, lds, s>>>(c->rows, c->n, dq, dc, R, K, doi, dod);                       \
     }
-    if (c->dim == 768) NVDB_REFINE3(768) else if (c->dim == 512) NVDB_REFINE3(512) else NVDB_REFINE3(256)
+    if (c->dim == 768) NVDB_REFINE3(768) else if (c->dim == 512) NVDB_REFINE3(512) else if (c->dim == 384) NVDB_REFINE3(384) else NVDB_REFINE3(256)
 #undef NVDB_REFINE3
     HIPCHK(c, hipGetLastError());
     return NVDB_OK;
@@ -1710,9 +1739,9 @@ nvdb_status nvdb_hip_refine_l2_topk(nvdb_hip_ctx* c, const float* queries, const
     (void)hipEventElapsedTime(&timing->kernel_ms, e1, e2);
     (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
     timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
-    const bool rows_kernel = c->opt_refine_v2 >= 2 && c->dtype == NVDB_DTYPE_F16 && (c->dim == 768 || c->dim == 512 || c->dim == 256);
+    const bool rows_kernel = c->opt_refine_v2 >= 2 && c->dtype == NVDB_DTYPE_F16 && refine3_dim(c->dim);
     timing->threads = rows_kernel ? 64 * REFINE3_WAVES : 256; timing->nwarps = rows_kernel ? REFINE3_WAVES : 4; timing->K = K; timing->R = R;
-    timing->shmem_bytes = rows_kernel ? static_cast<size_t>(REFINE3_WAVES) * (c->dim == 768 ? refine3_slot_bytes<768>() : c->dim == 512 ? refine3_slot_bytes<512>() : refine3_slot_bytes<256>())
+    timing->shmem_bytes = rows_kernel ? static_cast<size_t>(REFINE3_WAVES) * (c->dim == 768 ? refine3_slot_bytes<768>() : c->dim == 512 ? refine3_slot_bytes<512>() : c->dim == 384 ? refine3_slot_bytes<384>() : refine3_slot_bytes<256>())
                                       : (c->opt_refine_v2 ? 4 * 2 * 64 * 256 : 4 * 64 * 8 + 16);
   }
   return NVDB_OK;
