@@ -33,7 +33,9 @@ uint32_t nvdb_permuted_tile(uint32_t g, uint32_t n_tiles);
 
 /* The same for the int8 two-stage kernel (filter_i8w_kernel<768,2>, int8 d=768 corpus, nq > 128): stamped builds of the
  * production loop (variant 0) and of its timing-only ablations 1 = no stage 2 (the lo-plane pass never runs),
- * 2 = no stage-1 test either (stream + hi-plane MFMAs only), 3 = 2 + no per-tile barrier.  out4 as above. */
+ * 2 = no stage-1 test either (stream + hi-plane MFMAs only), 3 = 2 + no per-tile barrier; 10 = the software-pipelined build
+ * (filter_i8p_kernel), 11 = its structure alone, 12 = test without rare path.  out[0..3] as above, out[4], out[5] = rare-path
+ * entries and lo-plane MFMA blocks per launch (out must hold 6 floats). */
 nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* ctx, int variant, uint32_t nq, float seconds, float* out4);
 
 #ifdef __cplusplus

@@ -1418,7 +1418,8 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
 // The rare path is filter_i8w_kernel's: one flagged value -> deferred exact dot product (v_dot4), several -> lo-plane
 // MFMAs of the block.  Same survivors, same filter scores (test_int8_two_stage_kernel_matches_two_plane_kernel).
 // ------------------------------------------------------------------------------------------------
-template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6>
+// VAR (diagnostic builds, STAMP only; wrong results): 1 = no test and no rare path (the pipelined structure alone), 2 = test but no rare path
+template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
     const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
@@ -1431,13 +1432,14 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   constexpr int TROWS = FILTER_ROWS * MB;
   constexpr int NSTAGE = 3;
   constexpr int DATA_BYTES = TROWS * ROW_BYTES;
-  constexpr int STAGE_BYTES = DATA_BYTES + 4 * 1024;
+  constexpr int STAGE_BYTES = DATA_BYTES + 4 * 256;          // the tile + one 256-byte copy of its 64 row scales per wave
+  constexpr int NSLOT_DEFER = 4, SCRATCH_BYTES = NSLOT_DEFER * DIM;   // per wave: lo-plane rows of up to 4 deferred values
   constexpr int PIECES = DATA_BYTES / 1024;
   constexpr int PPW = PIECES / 4;
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
   static_assert(DIM % 256 == 0 && DIM <= 768, "row stride multiple of 256 bytes; int32 range of 128*H + L");
   static_assert(PIECES % 4 == 0 && KSTEPS % PPW == 0 && KSTEPS % 2 == 0 && KSTEPS >= 8, "shape");
-  static_assert(NSTAGE * STAGE_BYTES + 4096 <= 160 * 1024 && PPW + 1 < 64, "LDS / vmcnt range");
+  static_assert(NSTAGE * STAGE_BYTES + 4 * SCRATCH_BYTES <= 160 * 1024 && PPW + 1 < 64 && DIM % 16 == 0 && DIM / 16 <= 64, "LDS / vmcnt range");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1497,7 +1499,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     glds16(src_off[i], gbase + static_cast<uint64_t>(row0) * ROW_BYTES, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
   };
   auto issue_scales = [&](uint32_t row0, uint32_t buf) {
-    if (lane < 8 * MB) glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 1024);
+    if (lane < 8 * MB) glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 256);
   };
 #pragma unroll
   for (int st = 0; st < NSTAGE - 1; ++st) {
@@ -1510,39 +1512,56 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   uint32_t n_stage1 = 0, n_stage2 = 0;
   Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
 
-  // deferred single value (see filter_i8w_kernel): corpus row in 4 registers, the query's lo-plane row on its way into
-  // this wave's 1-KB LDS scratch; consumed at the end of a tile's second half, 13 younger loads behind it
-  char* scratch = smem + NSTAGE * STAGE_BYTES + wave * 1024;
-  const uint32_t lds_scratch = lds_base + NSTAGE * STAGE_BYTES + wave * 1024;
-  bool pend = false;
-  uint4 pend_x = make_uint4(0, 0, 0, 0);
-  int pend_H = 0;
-  float pend_scale = 0.f, pend_thr = 0.f, pend_inv = 0.f;
-  uint32_t pend_qid = 0, pend_row = 0;
-  auto consume_pending = [&](bool drain) {
-    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory");
-    int part = 0;
-    if (lane < DIM / 16) {
-      const uint4 lo = *reinterpret_cast<const uint4*>(scratch + lane * 16);
-      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.x), static_cast<int>(lo.x), part, false);
-      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.y), static_cast<int>(lo.y), part, false);
-      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.z), static_cast<int>(lo.z), part, false);
-      part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.w), static_cast<int>(lo.w), part, false);
+  // Deferred values (see filter_i8w_kernel): a value that passes stage 1 waits in one of 4 slots -- its corpus row in 4
+  // registers, its query's lo-plane row on the way into this wave's LDS scratch -- and is finished by an exact v_dot4
+  // product at the end of a tile's second half, when 13 younger loads stand behind it.  Only a block with more flagged values
+  // than free slots takes the lo-plane MFMAs (dense cases: first chunks, near-duplicate corpora).
+  char* scratch = smem + NSTAGE * STAGE_BYTES + wave * SCRATCH_BYTES;
+  const uint32_t lds_scratch = lds_base + NSTAGE * STAGE_BYTES + wave * SCRATCH_BYTES;
+  uint32_t pend_mask = 0;                          // uniform: occupied slots
+  uint32_t pend_old = 0;                           // ... of them, deferred during the PREVIOUS tile: those are consumed at the end of this one
+  uint32_t young_loads = 0;                        // deferred loads issued during this tile's first half (younger than every `pend_old` load)
+  uint4 pend_x[NSLOT_DEFER];
+  int pend_H[NSLOT_DEFER];
+  float pend_scale[NSLOT_DEFER], pend_thr[NSLOT_DEFER], pend_inv[NSLOT_DEFER];
+  uint32_t pend_qid[NSLOT_DEFER], pend_row[NSLOT_DEFER];
+#pragma unroll
+  for (int i = 0; i < NSLOT_DEFER; ++i) { pend_x[i] = make_uint4(0, 0, 0, 0); pend_H[i] = 0; pend_scale[i] = pend_thr[i] = pend_inv[i] = 0.f; pend_qid[i] = pend_row[i] = 0; }
+  // finish the slots in `which`: their lo-plane rows have landed once all but the `younger` newest loads are complete
+  auto consume_slots = [&](uint32_t which, uint32_t younger) {
+    switch (younger) {                             // s_waitcnt takes an immediate
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case PPW + 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory"); break;
+      case PPW + 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2) : "memory"); break;
+      case PPW + 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 3) : "memory"); break;
+      case PPW + 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 4) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 5) : "memory"); break;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    const float fv = static_cast<float>(pend_H * 128 + part) * pend_scale;
-    if (fv >= pend_thr) {
-      if (lane == 0 && wcnt < FILTER_LOGCAP) mylog[wcnt] = Hit{fv * pend_inv, pend_row, pend_qid, 0u};
-      ++wcnt;
+    for (int i = 0; i < NSLOT_DEFER; ++i) {
+      if (!(which & (1u << i))) continue;
+      int part = 0;
+      if (lane < DIM / 16) {
+        const uint4 lo = *reinterpret_cast<const uint4*>(scratch + i * DIM + lane * 16);
+        part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x[i].x), static_cast<int>(lo.x), part, false);
+        part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x[i].y), static_cast<int>(lo.y), part, false);
+        part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x[i].z), static_cast<int>(lo.z), part, false);
+        part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x[i].w), static_cast<int>(lo.w), part, false);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);        // exact: integer sum
+      const float fv = static_cast<float>(pend_H[i] * 128 + part) * pend_scale[i];
+      if (fv >= pend_thr[i]) {                     // (a slot given up by the block path carries thr = +inf)
+        if (lane == 0 && wcnt < FILTER_LOGCAP) mylog[wcnt] = Hit{fv * pend_inv[i], pend_row[i], pend_qid[i], 0u};
+        ++wcnt;
+      }
     }
-    pend = false;
+    pend_mask &= ~which;
   };
 
   intx16 acc0[NB], acc1[NB];                       // row block 0 / 1 of the tile in flight
   float scv[16];                                   // row scales of the block under test
-  float mx[NB];                                    // running max of H * scale per query block
+  float mx[NB][4];                                 // running max of H * scale per query block and group of 4 accumulator registers
   float4_t ar[RING];
 
   // one 32-row block's MFMAs (KSTEPS k-steps x NB query blocks) with `slot(s)` called after every k-step
@@ -1550,7 +1569,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256 + mb * FILTER_ROWS * ROW_BYTES);
   };
   auto load_scales = [&](const char* stage, int mb) {
-    const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 1024);
+    const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 256);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(sc_lds + 32 * mb + 8 * j + 4 * hsel);
@@ -1561,47 +1580,79 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   // v_max3 every second value: at most 3 VALU instructions behind one MFMA, inside its 24 free issue cycles
   float fprev = 0.f;
   auto test_value = [&](const intx16 (&a)[NB], int v) {
+    if constexpr (VAR == 1) return;
     const int nb = v / 16, r = v % 16;
     const float f = static_cast<float>(a[nb][r]) * scv[r];
-    if (r & 1) mx[nb] = vmax3(mx[nb], fprev, f); else fprev = f;
+    if (r & 1) mx[nb][r / 4] = vmax3(mx[nb][r / 4], fprev, f); else fprev = f;
   };
-  // rare path of one tested block: `a` its accumulators, `stage` / `row0` its tile, mb its row block
-  auto rare_path = [&](const intx16 (&a)[NB], const char* stage, uint32_t row0, int mb) {
+  auto reset_max = [&]() {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) mx[nb][g] = -__builtin_huge_valf();
+  };
+  auto any_flag = [&]() -> bool {                  // does any value of the tested block reach its first-stage threshold?
+    const float m0 = vmax3(vmax3(mx[0][0], mx[0][1], mx[0][2]), mx[0][3], mx[0][3]) - t1q[0];
+    const float m1 = vmax3(vmax3(mx[1][0], mx[1][1], mx[1][2]), mx[1][3], mx[1][3]) - t1q[1];
+    return __builtin_amdgcn_ballot_w64(vmax3(m0, m1, m1) >= 0.f) != 0;
+  };
+  // rare path of one tested block: `a` its accumulators, `stage` / `row0` its tile, mb its row block.  Returns the number of
+  // deferred loads it issued.  Per query block: the flagged group(s) of 4 registers -> the flagged values -> one slot each;
+  // a block with more flagged values than free slots gives its slots back and takes the lo-plane MFMAs instead.
+  auto rare_path = [&](const intx16 (&a)[NB], const char* stage, uint32_t row0, int mb) -> uint32_t {
     ++n_stage1;
-    uint32_t nflag = 0;
-    int c_H = 0;
-    float c_scale = 0.f, c_thr = 0.f, c_inv = 0.f;
-    uint32_t c_qid = 0, c_row = 0;
+    uint32_t issued = 0;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      if (!__builtin_amdgcn_ballot_w64(mx[nb] >= t1q[nb])) continue;
+      const uint32_t before = pend_mask;
+      bool overflow = false;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(static_cast<float>(a[nb][r]) * scv[r] >= t1q[nb]);
-        if (m) {
-          nflag += static_cast<uint32_t>(__builtin_popcountll(m));
+      for (int g = 0; g < 4; ++g) {
+        if (!__builtin_amdgcn_ballot_w64(mx[nb][g] >= t1q[nb])) continue;
+        // the group's 4 values, branch-free: per lane a 4-bit mask of the values that pass and (H, scale) of the last one
+        uint32_t bits = 0;
+        int hsel_v = 0;
+        float ssel_v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          const bool f = static_cast<float>(a[nb][r]) * scv[r] >= t1q[nb];
+          bits |= f ? (1u << j) : 0u;
+          hsel_v = f ? a[nb][r] : hsel_v;
+          ssel_v = f ? scv[r] : ssel_v;
+        }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(bits != 0);
+        while (m) {                                // flagged lanes (queries) of this group: almost always one
           const int L = __builtin_ctzll(m);
-          c_H = __builtin_amdgcn_readlane(a[nb][r], L);
-          c_scale = readlane_f(scv[r], L);
-          c_thr = readlane_f(thr_s[nb], L);
-          c_inv = readlane_f(inv_s[nb], L);
-          c_qid = readlane_u(qid[nb], L);
-          c_row = 32u * mb + (r & 3) + 8u * (r >> 2) + 4u * (static_cast<uint32_t>(L) >> 5);
+          m &= m - 1;
+          const uint32_t lb = readlane_u(bits, L);
+          if ((lb & (lb - 1)) != 0 || pend_mask == (1u << NSLOT_DEFER) - 1) { overflow = true; continue; }   // two values of one query in one group, or no slot left
+          const uint32_t r = 4u * g + (31u - static_cast<uint32_t>(__builtin_clz(lb)));
+          const uint32_t rowi = 32u * mb + (r & 3) + 8u * (r >> 2) + 4u * (static_cast<uint32_t>(L) >> 5);
+          bool placed = false;
+#pragma unroll
+          for (int i = 0; i < NSLOT_DEFER; ++i) {
+            if (placed || (pend_mask & (1u << i))) continue;
+            placed = true;
+            pend_H[i] = __builtin_amdgcn_readlane(hsel_v, L);
+            pend_scale[i] = readlane_f(ssel_v, L);
+            pend_thr[i] = readlane_f(thr_s[nb], L);
+            pend_inv[i] = readlane_f(inv_s[nb], L);
+            pend_qid[i] = readlane_u(qid[nb], L);
+            pend_row[i] = rowi + row0;
+            // its corpus row: chunk l of row i sits at position l ^ (i & 15) of the stage's row image
+            if (lane < DIM / 16) pend_x[i] = *reinterpret_cast<const uint4*>(stage + rowi * ROW_BYTES + ((static_cast<uint32_t>(lane) ^ (rowi & 15u)) << 4));
+            if (lane < DIM / 16) glds16(static_cast<uint32_t>(lane) * 16u, qlo + static_cast<uint64_t>(pend_qid[i]) * DIM, lds_scratch + i * DIM);
+            pend_mask |= 1u << i;
+            ++issued;
+          }
         }
       }
-    }
-    if (nflag == 1 && !pend) {                     // the scratch slot is free: defer this one value
-      pend_H = c_H; pend_scale = c_scale; pend_thr = c_thr; pend_inv = c_inv; pend_qid = c_qid;
-      if (lane < DIM / 16) pend_x = *reinterpret_cast<const uint4*>(stage + c_row * ROW_BYTES + ((static_cast<uint32_t>(lane) ^ (c_row & 15u)) << 4));
-      if (lane < DIM / 16) glds16(static_cast<uint32_t>(lane) * 16u, qlo + static_cast<uint64_t>(c_qid) * DIM, lds_scratch);
-      pend_row = c_row + row0;
-      pend = true;
-      return;
-    }
-    if (nflag == 0) return;
+      if (!overflow) continue;
+      // ---- too many for the slots: this block's deferrals are void (their slots stay busy until consumed, with a threshold
+      //      nothing reaches) and the lo plane of this (row block, query block) goes to the matrix cores ----
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      if (!__builtin_amdgcn_ballot_w64(mx[nb] >= t1q[nb])) continue;
+      for (int i = 0; i < NSLOT_DEFER; ++i) if ((pend_mask & ~before) & (1u << i)) pend_thr[i] = __builtin_huge_valf();
       ++n_stage2;
       const signed char* ql = qlo + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 16 * hsel;
       intx16 lo;
@@ -1630,6 +1681,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
         }
       }
     }
+    return issued;
   };
 
   uint32_t sync_strikes = 0;
@@ -1657,7 +1709,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     constexpr int NSLOT = 2 * KSTEPS, W0 = NSLOT / 4 < 8 ? NSLOT / 4 : 8, VPS = (32 + NSLOT - W0 - 1) / (NSLOT - W0);   // values per slot: 1 at d = 768
     // ---- first half: block 0 of tile t  ||  test of block 1 of tile t-1 (t == 0: garbage, tested and ignored) ----------
     load_scales(prev_stage, 1);
-    mx[0] = mx[1] = -__builtin_huge_valf();
+    reset_max();
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(stage, s, 0);
 #pragma unroll
@@ -1674,11 +1726,13 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (t > 0 && __builtin_amdgcn_ballot_w64(mx[0] >= t1q[0] || mx[1] >= t1q[1])) rare_path(acc1, prev_stage, tile_row0(t - 1), 1);
+    young_loads = 0;
+    if (VAR == 0 && t > 0 && any_flag()) young_loads = rare_path(acc1, prev_stage, tile_row0(t - 1), 1);
+    if constexpr (VAR != 0) { asm volatile("" ::"v"(mx[0][0]), "v"(mx[1][0]), "v"(mx[0][1]), "v"(mx[1][1]), "v"(mx[0][2]), "v"(mx[1][2]), "v"(mx[0][3]), "v"(mx[1][3])); }   // keep this half's test alive
     __builtin_amdgcn_s_barrier();                                          // B: nobody reads the stage of tile t-1 any more
     // ---- second half: block 1 of tile t  ||  loads of tile t+2, test of block 0 of tile t ---------------------------
     load_scales(stage, 0);
-    mx[0] = mx[1] = -__builtin_huge_valf();
+    reset_max();
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(stage, s, 1);
 #pragma unroll
@@ -1698,19 +1752,22 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
       if (s == 0) issue_scales(next_row0, next_buf);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (pend) consume_pending(false);                                      // PPW + 1 younger loads behind it: this tile's
-    if (__builtin_amdgcn_ballot_w64(mx[0] >= t1q[0] || mx[1] >= t1q[1])) rare_path(acc0, stage, tile_row0(t), 0);
+    // what was deferred during the PREVIOUS tile is at least one tile old now; behind it: this tile's deferred loads and its PPW + 1 pieces
+    if (pend_old) consume_slots(pend_old, PPW + 1 + young_loads);
+    if (VAR == 0 && any_flag()) rare_path(acc0, stage, tile_row0(t), 0);
+    pend_old = pend_mask;                                                  // everything deferred during this tile: due at the end of the next
+    if constexpr (VAR != 0) { asm volatile("" ::"v"(mx[0][0]), "v"(mx[1][0]), "v"(mx[0][1]), "v"(mx[1][1]), "v"(mx[0][2]), "v"(mx[1][2]), "v"(mx[0][3]), "v"(mx[1][3])); }
   }
   if (wave_has_queries) {                          // block 1 of the last tile
     const char* last_stage = smem + ((NT - 1) % NSTAGE) * STAGE_BYTES;
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     load_scales(last_stage, 1);
-    mx[0] = mx[1] = -__builtin_huge_valf();
+    reset_max();
 #pragma unroll
     for (int v = 0; v < 32; ++v) test_value(acc1, v);
-    if (pend) consume_pending(true);
-    if (__builtin_amdgcn_ballot_w64(mx[0] >= t1q[0] || mx[1] >= t1q[1])) rare_path(acc1, last_stage, tile_row0(NT - 1), 1);
-    if (pend) consume_pending(true);
+    if (pend_mask) consume_slots(pend_mask, 0);
+    if (VAR == 0 && any_flag()) rare_path(acc1, last_stage, tile_row0(NT - 1), 1);
+    if (pend_mask) consume_slots(pend_mask, 0);
   }
   if constexpr (STAMP) {
     const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c, dr = __builtin_amdgcn_s_memrealtime() - stamp_r;

@@ -39,6 +39,7 @@ std::string g_create_err;
 
 constexpr uint32_t SELECT_MAX_CAP = 8192;     // 64 KB of LDS in select_kernel
 constexpr uint32_t WAVE_KMAX = 64;            // k the wavefront-resident top-k lists hold (entry j in lane j)
+constexpr uint32_t FILTER_KMAX = 1024;        // k the filter path's 8192-entry lists (and its bootstrap over 8k tile maxima) hold
 constexpr float FILTER_REL_F16 = 7.5e-4f;     // |filter - reference| <= REL * ||q|| * max||x||   (DESIGN.md "error bound")
 
 struct DevBuf {
@@ -596,12 +597,13 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   }
 #define NVDB_I8P_LAUNCH(SYNCV, PROG, MASK, LEAD)                                                                                  \
   {                                                                                                                             \
+    constexpr size_t ldsp = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + 4 * 256) + 16 * DIM;   /* stages + 4 waves x 4 deferred lo-plane rows */ \
     const void* fn = reinterpret_cast<const void*>(filter_i8p_kernel<DIM, SYNCV>);                                              \
     if (!c->lds_attr_set.count(fn)) {                                                                                           \
-      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
+      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsp)));                   \
       c->lds_attr_set.insert(fn);                                                                                               \
     }                                                                                                                           \
-    hipExtLaunchKernelGGL((filter_i8p_kernel<DIM, SYNCV>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
+    hipExtLaunchKernelGGL((filter_i8p_kernel<DIM, SYNCV>), dim3(nwg), dim3(256), ldsp, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
   }
@@ -789,6 +791,13 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   uint32_t cap = cap_override ? cap_override : c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : std::max<uint32_t>(c->cap_hint, nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
   if (cap < 4 * k_eff) cap = std::min<uint32_t>(SELECT_MAX_CAP, 4 * k_eff);
+  // 64 < k <= 1024 on the filter path (its kernels do not depend on k; the lists do): the longest lists, a bootstrap over
+  // 8k tile maxima and chunks small enough that k * (growth - 1) new survivors + the k kept ones + the error band fit.
+  // Anything else beyond the wavefront lists' 64 entries takes the any-k path.
+  const bool k_wide = k_eff > WAVE_KMAX;
+  const bool wide_on_filter = k_wide && path == 2 && force_path != 1 && k_eff <= FILTER_KMAX && c->opt_mfma_boot &&
+                              (c->dtype == NVDB_DTYPE_I8 || c->fdim <= 768) && c->n >= 2ull * FILTER_ROWS * 8 * k_eff;
+  if (wide_on_filter) cap = SELECT_MAX_CAP;
   // queries per filter workgroup: 256 / 128, or 64 on the K-split build (dims > 1536)
   const uint32_t QPB = (c->dtype != NVDB_DTYPE_I8 && c->fdim > 1536) ? 64u : 128u * filter_nb(c, nq);
   const uint32_t QT = (nq + QPB - 1) / QPB;
@@ -814,8 +823,8 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   c->last_nq = nq; c->last_cap = cap; c->last_filter = (path == 2);
   c->ev_filter.clear();
 
-  if (k_eff > WAVE_KMAX) {
-    // beyond the wavefront-resident lists (k <= 64): the any-k path (scores -> radix select -> sort)
+  if (k_wide && !wide_on_filter) {
+    // beyond the wavefront-resident lists (k <= 64) and not on the filter path: the any-k path (scores -> radix select -> sort)
     c->stats.path = 3; c->last_filter = false;
     return search_largek(c, s, dev_q, nq, k, dev_out_ids, dev_out_scores);
   }
@@ -860,7 +869,8 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // chunk i covers (growth-1) x the rows seen before it.  fp16: 8 (flat between 4 and 8).  int8 batches > 128: 3 --
   // tighter thresholds earlier mean fewer tiles for which the two-stage kernel needs the lo plane, and a tile costs
   // what its slowest wave costs (profiles/r01d_i8_growth_sweep.txt)
-  const uint64_t growth = c->opt_growth > 0 ? static_cast<uint64_t>(c->opt_growth) : (i8_two_stage(c) && nq > 128 ? 3u : 8u);
+  uint64_t growth = c->opt_growth > 0 ? static_cast<uint64_t>(c->opt_growth) : (i8_two_stage(c) && nq > 128 ? 3u : 8u);
+  if (k_wide) growth = std::max<uint64_t>(2, std::min<uint64_t>(growth, cap / (3ull * k_eff)));     // k * (growth - 1) + k + band <= cap
   // T tile maxima with T >= 8k: their k-th largest is then close to the k-th best of the 32*T rows (with T == k it
   // would be the smallest tile maximum, a uselessly weak threshold)
   const uint32_t boot_rows = FILTER_ROWS * std::max<uint32_t>(64u, 8u * k_eff);
@@ -914,7 +924,8 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     size = static_cast<uint64_t>(r) * (growth - 1);   // rows seen so far x (growth-1)
   }
   if (n_al < n) {   // ragged tail of an adopted corpus: exact scores, pruned by the current thresholds
-    if ((st = launch_scan_exact(c, s, n_al, n, dev_q, nq, k_eff, static_cast<const float*>(c->thr.p), cap, 0))) return st;
+    // (fewer than one tile of rows per workgroup: the wavefront lists' 64 entries keep every row that clears the threshold)
+    if ((st = launch_scan_exact(c, s, n_al, n, dev_q, nq, std::min(k_eff, WAVE_KMAX), static_cast<const float*>(c->thr.p), cap, 0))) return st;
     c->stats.rows_scanned += static_cast<uint64_t>(n - n_al) * QT;
   }
   if ((st = launch_rescore(c, s, dev_q, nq, cap))) return st;
@@ -1510,28 +1521,33 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
           filter_rows_i8(c), filter_scales_i8(c), 0, n_al, qhi, qlo, nq, QT, static_cast<const float*>(c->thr.p),                \
           static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<const float*>(c->qdelta.p),  \
           static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap, I8W_TILE_ROWS), static_cast<uint32_t*>(c->prog.p),        \
-          static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), nullptr);                       \
+          static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), static_cast<uint32_t*>(c->misc.p) + 4);  \
     }                                                                                                                            \
   }
   for (;;) {
     const bool last = std::chrono::duration<float>(std::chrono::steady_clock::now() - t_start).count() >= seconds;
-    if (last) HIPCHK(c, hipEventRecord(e0, c->stream));
+    if (last) { HIPCHK(c, hipMemsetAsync(static_cast<uint32_t*>(c->misc.p) + 4, 0, 8, c->stream)); HIPCHK(c, hipEventRecord(e0, c->stream)); }
     switch (variant) {
       case 0: NVDB_CLK_I8(0) break;
       case 1: NVDB_CLK_I8(1) break;
       case 2: NVDB_CLK_I8(2) break;
       case 3: NVDB_CLK_I8(3) break;
-      case 10: {                                  // the software-pipelined production build, stamped
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_i8p_kernel<768, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        for (uint32_t r = 0; r < burst; ++r) {
-          HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, prog_bytes, c->stream));
-          filter_i8p_kernel<768, true, true><<<nwg, 256, lds, c->stream>>>(
-              filter_rows_i8(c), filter_scales_i8(c), 0, n_al, qhi, qlo, nq, QT, static_cast<const float*>(c->thr.p),
-              static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<const float*>(c->qdelta.p),
-              static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap, I8W_TILE_ROWS), static_cast<uint32_t*>(c->prog.p),
-              static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), nullptr);
-        }
-      } break;
+#define NVDB_CLK_I8P(V)                                                                                                          \
+      {                                                                                                                          \
+        constexpr size_t ldsp = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + 4 * 256) + 16 * 768;                             \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_i8p_kernel<768, true, true, 6, V>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsp))); \
+        for (uint32_t r = 0; r < burst; ++r) {                                                                                   \
+          HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, prog_bytes, c->stream));                                                     \
+          filter_i8p_kernel<768, true, true, 6, V><<<nwg, 256, ldsp, c->stream>>>(                                               \
+              filter_rows_i8(c), filter_scales_i8(c), 0, n_al, qhi, qlo, nq, QT, static_cast<const float*>(c->thr.p),            \
+              static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<const float*>(c->qdelta.p), \
+              static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap, I8W_TILE_ROWS), static_cast<uint32_t*>(c->prog.p),    \
+              static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), static_cast<uint32_t*>(c->misc.p) + 4); \
+        }                                                                                                                        \
+      }
+      case 10: NVDB_CLK_I8P(0) break;             // the software-pipelined production build, stamped
+      case 11: NVDB_CLK_I8P(1) break;             // ... its structure alone: no test, no rare path
+      case 12: NVDB_CLK_I8P(2) break;             // ... test in the MFMA shadow, rare path never taken
       default: return fail(c, NVDB_ERR_INVALID, "debug: unknown variant");
     }
     HIPCHK(c, hipGetLastError());
@@ -1545,6 +1561,7 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
 #undef NVDB_CLK_I8
+#undef NVDB_CLK_I8P
   std::vector<uint64_t> stamps(static_cast<size_t>(nwg) * 2);
   HIPCHK(c, hipMemcpy(stamps.data(), static_cast<const char*>(c->prog.p) + prog_bytes, stamp_bytes, hipMemcpyDeviceToHost));
   std::vector<float> ghz;
@@ -1555,6 +1572,10 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
   out4[1] = ghz.empty() ? 0.f : ghz[ghz.size() / 2];
   out4[2] = ghz.empty() ? 0.f : ghz.front();
   out4[3] = ghz.empty() ? 0.f : ghz.back();
+  uint32_t counts[2] = {0, 0};                      // rare-path entries / lo-plane MFMA blocks of the timed burst
+  HIPCHK(c, hipMemcpy(counts, static_cast<uint32_t*>(c->misc.p) + 4, 8, hipMemcpyDeviceToHost));
+  out4[4] = static_cast<float>(counts[0]) / burst;
+  out4[5] = static_cast<float>(counts[1]) / burst;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return NVDB_OK;
 }

@@ -213,16 +213,21 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx, oracle, nq, k, d):
         queries[5] = np.round(queries[5] * 40) / 40          # few distinct levels
     ctx.set_option("path", 2)
     res, stats = {}, {}
-    for wide in (0, 1):
+    # 0: two-plane kernel; 1: two-stage, software-pipelined build for batches > 128 (the default); 2: two-stage, filter_i8w_kernel
+    for var, (wide, pipe) in enumerate(((0, 1), (1, 1), (1, 0))):
         ctx.set_option("i8_wide", wide)
-        res[wide] = ctx.search_batch(queries, k)
-        stats[wide] = ctx.stats()
-        assert stats[wide]["path"] == 2 and stats[wide]["bound_violations"] == 0 and stats[wide]["overflow_queries"] == 0, stats[wide]
+        ctx.set_option("i8_pipe", pipe)
+        res[var] = ctx.search_batch(queries, k)
+        stats[var] = ctx.stats()
+        assert stats[var]["path"] == 2 and stats[var]["bound_violations"] == 0 and stats[var]["overflow_queries"] == 0, stats[var]
     ctx.set_option("i8_wide", 1)
+    ctx.set_option("i8_pipe", 1)
     ctx.set_option("path", 0)
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
-    assert stats[0]["candidates"] == stats[1]["candidates"]
-    assert stats[0]["i8_stage1_tiles"] == 0 and 0 < stats[1]["i8_stage2_blocks"] <= 4 * stats[1]["i8_stage1_tiles"], stats
+    for var in (1, 2):
+        assert np.array_equal(res[0][0], res[var][0]) and np.array_equal(res[0][1].view(np.uint32), res[var][1].view(np.uint32)), var
+        assert stats[0]["candidates"] == stats[var]["candidates"], var
+        assert stats[var]["i8_stage1_tiles"] > 0, stats[var]       # some values passed the hi-plane test and were finished exactly
+    assert stats[0]["i8_stage1_tiles"] == 0
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[1][0], res[1][1], k, f"i8-wide/nq{nq}")
 
 
@@ -600,6 +605,30 @@ def test_any_k_matches_oracle(ctx, oracle, name, k, tag):
         assert_topk_equal(ids[qi], sc[qi], oid[qi], osc[qi], score_of=lambda i: allsc[i], what=f"anyk/{name}/{tag}/k{k}/q{qi}")
         order = np.lexsort((ids[qi], -sc[qi].astype(np.float64)))
         assert np.array_equal(order, np.arange(ids.shape[1])), "canonical (score desc, id asc) order"
+
+
+@pytest.mark.parametrize("tag,k,nq", [("f16", 100, 300), ("f16", 1000, 200), ("i8", 100, 256), ("i8", 1024, 40), ("f32", 200, 64)])
+def test_k_up_to_1024_rides_the_filter_path(oracle, tag, k, nq):
+    """64 < k <= 1024: the MFMA filter's lists (8192 entries), a bootstrap over 8k tile maxima and small chunks; results must
+    equal the any-k path (forced with path = 1) for every query and the oracle for a few."""
+    n, d = 600_000 + 7, 768
+    dt = {"f16": nvdb_amd.DT_F16, "i8": nvdb_amd.DT_I8, "f32": nvdb_amd.DT_F32}[tag]
+    c = nvdb_amd.HipContext(0)
+    c.generate_corpus(SEED + 7, n, d, dt)
+    queries = nvdb_amd.synth_rows_f32(SEED + 8, 0, nq, d)
+    ids, sc = c.search_batch(queries, k)
+    st = c.stats()
+    assert st["path"] == 2 and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    c.set_option("path", 1)
+    ide, sce = c.search_batch(queries, k)
+    assert c.stats()["path"] == 3
+    c.set_option("path", 0)
+    assert np.array_equal(ids, ide) and np.array_equal(sc.view(np.uint32), sce.view(np.uint32))
+    base, scales = c.download_rows(0, n)
+    sub = [0, nq // 2, nq - 1]
+    oid, osc = oracle.flat_topk(base, {"f16": po.DT_F16, "i8": po.DT_I8, "f32": po.DT_F32}[tag], queries[sub], k, scales)
+    assert np.array_equal(ids[sub], oid) and np.array_equal(sc[sub].view(np.uint32), osc.view(np.uint32))
+    c.close()
 
 
 def test_any_k_large_lists_sorted_in_global_memory(oracle):

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""int8 batch 1024: pass time vs chunk growth (and the candidate counts it leaves), interleaved rounds in one process."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd"))
+import numpy as np, torch, nvdb_amd
+n, d, B, K = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, 768, 1024, 10
+dev = torch.device("cuda", 0)
+torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+ctx = nvdb_amd.HipContext(0)
+ctx.generate_corpus(20240613, n, d, nvdb_amd.DT_I8)
+q = torch.from_numpy(nvdb_amd.synth_rows_f32(20240614, 0, 4 * B, d)).to(dev)
+oi = torch.empty((B, K), dtype=torch.int64, device=dev); os_ = torch.empty((B, K), dtype=torch.float32, device=dev)
+for rnd in range(2):
+    for g in (3, 4, 5, 8):
+        ctx.set_option("chunk_growth", g)
+        strm = torch.cuda.current_stream().cuda_stream
+        for i in range(2): ctx.search_batch_dev(q[i * B:(i + 1) * B].data_ptr(), B, K, oi.data_ptr(), os_.data_ptr(), strm)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(8): ctx.search_batch_dev(q[(i % 4) * B:(i % 4 + 1) * B].data_ptr(), B, K, oi.data_ptr(), os_.data_ptr(), strm)
+        torch.cuda.synchronize(); el = (time.perf_counter() - t0) / 8
+        st = ctx.search_check()
+        print(f"round {rnd} growth {g:2d}: {el * 1e3:.3f} ms per pass = {B / el:.0f} queries/s = {2.0 * B * n * d / el / 1e12:.0f} TOP/s; chunks {st['chunks']} "
+              f"stage1 {st['i8_stage1_tiles']} stage2 blocks {st['i8_stage2_blocks']} candidates/query {st['candidates'] / B:.1f}", flush=True)

@@ -17,9 +17,9 @@ q = nvdb_amd.synth_rows_f32(20240614, 0, nq, 768)
 ctx.set_option("path", 2); ctx.search_batch(q, 10)
 st = ctx.stats()
 print(f"search: {st}", flush=True)
-names = {10: "software-pipelined build (filter_i8p_kernel, the default)", 0: "filter_i8w_kernel loop", 1: "no stage 2 (lo plane never multiplied)", 2: "no stage-1 test either (stream + hi-plane MFMAs)", 3: "the same without the per-tile barrier"}
-for var in (10, 0, 1, 2, 3, 10, 0):
-    out = (C.c_float * 4)()
+names = {10: "software-pipelined build (filter_i8p_kernel, the default)", 11: "pipelined structure alone (no test, no rare path)", 12: "pipelined, test in the MFMA shadow, rare path never taken", 0: "filter_i8w_kernel loop", 1: "no stage 2 (lo plane never multiplied)", 2: "no stage-1 test either (stream + hi-plane MFMAs)", 3: "the same without the per-tile barrier"}
+for var in (10, 12, 11, 0, 10, 12):
+    out = (C.c_float * 6)()
     rc = lib.nvdb_hip_debug_clock_i8(ctx.h, var, nq, secs, out)
     assert rc == 0, lib.nvdb_hip_last_error(ctx.h)
     ms, med, lo, hi = out[0], out[1], out[2], out[3]
@@ -27,4 +27,5 @@ for var in (10, 0, 1, 2, 3, 10, 0):
     mfma_cycles = (n / 64) / 64.0 * 96 * 32            # per SIMD: tiles per workgroup x 96 v_mfma_i32_32x32x32_i8 x 32 cycles
     busy = mfma_cycles / (ms * 1e-3 * med * 1e9)
     print(f"[{names[var]}] whole-corpus launch {ms:.3f} ms = {tops:.0f} TOP/s algorithmic (hi plane only: half the int8 work of the two-plane kernel); "
-          f"in-kernel clock median {med:.3f} GHz (min {lo:.3f}, max {hi:.3f}); MFMA pipe busy {busy:.3f}; cycles per tile {3072 / busy:.0f}", flush=True)
+          f"in-kernel clock median {med:.3f} GHz (min {lo:.3f}, max {hi:.3f}); MFMA pipe busy {busy:.3f}; cycles per tile {3072 / busy:.0f}; "
+          f"rare-path entries {out[4]:.0f}, lo-plane MFMA blocks {out[5]:.0f} per launch ({n // 64 * 16 * 2} wave-halves)", flush=True)
