@@ -560,10 +560,14 @@ def main():
             for _ in range(3):
                 _, _, t = cr.refine_l2_topk(rq, cand, K, want_timing=True)
                 best = t.kernel_ms if best is None else min(best, t.kernel_ms)
+            cr.set_option("refine_pinned", 1)                  # the reference's CUDA_PINNED=1: pinned host staging of the call's buffers
+            _, _, tp = cr.refine_l2_topk(rq, cand, K, want_timing=True)
+            _, _, tp = cr.refine_l2_topk(rq, cand, K, want_timing=True)
             cr.close()
             gb = float((cand != 0xFFFFFFFF).sum()) * D * 2 / 1e9
             extras["refine"] = {"workload": f"exact-L2 refine N={NR} Q={QR} R={RR} K={K} fp16", "kernel": "refine_l2_rows_kernel<768>",
                                 "kernel_ms": best, "us_per_query": best * 1e3 / QR, "h2d_ms": t.h2d_ms, "d2h_ms": t.d2h_ms,
+                                "pinned": {"h2d_ms": tp.h2d_ms, "kernel_ms": tp.kernel_ms, "d2h_ms": tp.d2h_ms, "total_ms": tp.total_ms},
                                 "gather_GBps": gb / (best * 1e-3), "hbm_frac": gb / (best * 1e-3) / PEAK_HBM_GBPS}
             del cand, rq
             # (4) the north star's target point: N=100M (153.6 GB resident on this one GPU), batch 64 (HBM-bound) and 1024

@@ -92,10 +92,16 @@ def test_rendezvous_registers_and_hand_placed_instructions(codegen):
         if "s_load_dwordx8 s[88:95]" in body:
             n_sync += 1
             assert v["sgpr"] >= 96, (key, v)                             # s88..s95 are inside the kernel's allocation
-            # the block's own eight moves are the only readers of s88..s95
-            readers = re.findall(r"^\s*(\S+)\s+[^\n]*\bs(8[89]|9[0-5])\b", body, flags=re.M)
-            assert all(op in ("s_load_dwordx8", "s_mov_b32") for op, _ in readers), (key, set(op for op, _ in readers))
+            # the block is intact: the load, its wait, then the eight moves out of s88..s95 (nothing in between)
+            for blk in re.finditer(r"s_load_dwordx8 s\[88:95\][^\n]*\n\s*s_waitcnt lgkmcnt\(0\)\n((?:\s*s_mov_b32 s\d+, s(?:8[89]|9[0-5])\n){8})", body):
+                assert sorted(re.findall(r", s(\d+)\n", blk.group(1))) == [str(x) for x in range(88, 96)]
+            assert len(re.findall(r"s_load_dwordx8 s\[88:95\]", body)) == len(re.findall(r"s_load_dwordx8 s\[88:95\][^\n]*\n\s*s_waitcnt lgkmcnt\(0\)\n(?:\s*s_mov_b32 s\d+, s(?:8[89]|9[0-5])\n){8}", body))
     assert n_sync >= 8
+    # the compiler keeps nothing live in s88..s95 across the block because the asm statement declares them clobbered
+    src = open(os.path.join(PKG, "csrc", "kernels_filter.h")).read()
+    blk = src[src.index('asm volatile("s_load_dwordx8 s[88:95]'):]
+    blk = blk[:blk.index(");") + 2]
+    assert all(f'"s{r}"' in blk for r in range(88, 96)), "clobber list of the sibling rendezvous"
     # headline kernel: 192 MFMAs per tile and wave pair -> 96 in the 8-wave build's loop body, fed from AGPRs; the
     # compiler must not have copied fragments into VGPRs (v_accvgpr_read inside the loop)
     k = _find(by_name, "filter_f16_m16_kernelILi768ELi4ELb1ELb0ELi0ELi2ELi2ELi8E")
