@@ -435,7 +435,7 @@ def main():
                                + (" (BASELINE configs[1])" if (N, world) == (ROWS_1GPU, 1) else " (BASELINE configs[3])" if N == ROWS_SHARDED else ""),
                    "rows_total": N, "rows_per_gpu": hi - lo, "batch": B, "k": K, "dim": D,
                    "parallelism": "1 GPU" if world == 1 else f"corpus row-sharded x{world}, RCCL all-gather of per-shard top-k",
-                   "series": None if world == 1 else "strong scaling over the 100M-row corpus; its 1-GPU point is extras.fp16_100M_batch1024 of the --gpus 1 line"},
+                   "series": "strong scaling over the 100M-row corpus; its 1-GPU point is extras.fp16_100M_batch1024 of the --gpus 1 line" if (world > 1 and N == ROWS_SHARDED) else None},
         "effective_hbm_GBps": (N * bpr / 1e9) / (ms_per_step * 1e-3),          # corpus bytes / pass time, all GPUs
         "parity": parity, "merge_check": merge_check,
         "self_check": "every timed step checked (sticky flags): no list overflow, no bound violation",
@@ -446,7 +446,7 @@ def main():
         sec = kt["ms"] * 1e-3
         ach = kt["flops"] / sec / 1e12
         peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_I8_TOPS
-        kname = (("filter_f16_m16_kernel<768> (8 waves x 32 queries)" if B > 128 else "filter_f16_kernel<768,1>") if args.dtype == "f16" else ("filter_i8w_kernel<768,2>" if B > 128 else "filter_i8w_kernel<768,1>"))
+        kname = (("filter_f16_m16_kernel<768> (8 waves x 32 queries)" if B > 128 else "filter_f16_kernel<768,1>") if args.dtype == "f16" else ("filter_i8p_kernel<768> (software-pipelined two-stage build)" if B > 128 else "filter_i8w_kernel<768,1>"))
         gbps = kt["bytes"] / sec / 1e9
         # ridge point: intensity = 2*B*dim flop per row / row bytes  vs  peak flop / peak bytes
         hbm_bound = (2.0 * B * D / bpr) < (peak * 1e12 / (PEAK_HBM_GBPS * 1e9))
