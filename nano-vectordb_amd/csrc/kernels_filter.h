@@ -1084,6 +1084,16 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
 #define NVDB_MFMA_I8_ZERO_V(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b))
 #define NVDB_MFMA_I8_ACC_V(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 
+// sum of an int over the 64 lanes, uniform result: two quad permutes, half-row mirror, row mirror (DPP, no LDS round trips),
+// then the four row sums through SGPRs
+__device__ __forceinline__ int wave_sum_i32(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);   // row_mirror: every lane of a 16-lane row holds the row's sum
+  return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
+}
+
 __device__ __forceinline__ int imax3(int a, int b, int c) {
   int r;
   asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -1228,8 +1238,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
       part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.z), static_cast<int>(lo.z), part, false);
       part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.w), static_cast<int>(lo.w), part, false);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);          // exact: integer sum
+    part = wave_sum_i32(part);                                             // exact: integer sum
     const float fv = static_cast<float>(pend_H * 128 + part) * pend_scale;
     if (fv >= pend_thr) {
       if (lane == 0 && wcnt < FILTER_LOGCAP) mylog[wcnt] = Hit{fv * pend_inv, pend_row, pend_qid, 0u};
@@ -1418,7 +1427,8 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
 // The rare path is filter_i8w_kernel's: one flagged value -> deferred exact dot product (v_dot4), several -> lo-plane
 // MFMAs of the block.  Same survivors, same filter scores (test_int8_two_stage_kernel_matches_two_plane_kernel).
 // ------------------------------------------------------------------------------------------------
-// VAR (diagnostic builds, STAMP only; wrong results): 1 = no test and no rare path (the pipelined structure alone), 2 = test but no rare path
+// VAR (diagnostic builds, STAMP only; wrong results): 1 = no test and no rare path (the pipelined structure alone), 2 = test but no rare path,
+// 3 = rare path without consuming the deferred values, 4 = rare path entered and left at once
 template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
@@ -1529,6 +1539,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   for (int i = 0; i < NSLOT_DEFER; ++i) { pend_x[i] = make_uint4(0, 0, 0, 0); pend_H[i] = 0; pend_scale[i] = pend_thr[i] = pend_inv[i] = 0.f; pend_qid[i] = pend_row[i] = 0; }
   // finish the slots in `which`: their lo-plane rows have landed once all but the `younger` newest loads are complete
   auto consume_slots = [&](uint32_t which, uint32_t younger) {
+    if constexpr (VAR == 3) { pend_mask &= ~which; return; }
     switch (younger) {                             // s_waitcnt takes an immediate
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
       case PPW + 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 1) : "memory"); break;
@@ -1548,8 +1559,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
         part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x[i].z), static_cast<int>(lo.z), part, false);
         part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x[i].w), static_cast<int>(lo.w), part, false);
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);        // exact: integer sum
+      part = wave_sum_i32(part);                                           // exact: integer sum
       const float fv = static_cast<float>(pend_H[i] * 128 + part) * pend_scale[i];
       if (fv >= pend_thr[i]) {                     // (a slot given up by the block path carries thr = +inf)
         if (lane == 0 && wcnt < FILTER_LOGCAP) mylog[wcnt] = Hit{fv * pend_inv[i], pend_row[i], pend_qid[i], 0u};
@@ -1576,14 +1586,18 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
       scv[4 * j] = v.x; scv[4 * j + 1] = v.y; scv[4 * j + 2] = v.z; scv[4 * j + 3] = v.w;
     }
   };
-  // value v (0..31) of a block's stage-1 test: query block v / 16, accumulator register v % 16 -- cvt + mul, and a
-  // v_max3 every second value: at most 3 VALU instructions behind one MFMA, inside its 24 free issue cycles
-  float fprev = 0.f;
-  auto test_value = [&](const intx16 (&a)[NB], int v) {
+  // Stage-1 test of a block (32 values: query block v / 16, accumulator register v % 16), software-pipelined over the MFMA
+  // slots so that the (at most 3) VALU instructions behind one MFMA never depend on each other: slot j converts the values
+  // of step j, multiplies those of step j - 1 by their row scales and folds those of step j - 2 into the running maxima.
+  float tc[32], tm[32];
+  auto test_step = [&](const intx16 (&a)[NB], int j, int vps) {
     if constexpr (VAR == 1) return;
-    const int nb = v / 16, r = v % 16;
-    const float f = static_cast<float>(a[nb][r]) * scv[r];
-    if (r & 1) mx[nb][r / 4] = vmax3(mx[nb][r / 4], fprev, f); else fprev = f;
+#pragma unroll
+    for (int v = j * vps; v < (j + 1) * vps; ++v) if (v >= 0 && v < 32) tc[v] = static_cast<float>(a[v / 16][v % 16]);
+#pragma unroll
+    for (int v = (j - 1) * vps; v < j * vps; ++v) if (v >= 0 && v < 32) tm[v] = tc[v] * scv[v % 16];
+#pragma unroll
+    for (int v = (j - 2) * vps; v < (j - 1) * vps; ++v) if (v >= 0 && v < 32 && (v & 1)) mx[v / 16][(v % 16) / 4] = vmax3(mx[v / 16][(v % 16) / 4], tm[v - 1], tm[v]);
   };
   auto reset_max = [&]() {
 #pragma unroll
@@ -1591,17 +1605,21 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) mx[nb][g] = -__builtin_huge_valf();
   };
-  auto any_flag = [&]() -> bool {                  // does any value of the tested block reach its first-stage threshold?
+  float flagv = -1.f;                              // >= 0 iff some value of the tested block reaches its first-stage threshold
+  auto combine_flags = [&]() {                     // behind the half's last MFMA
+    if constexpr (VAR == 1) return;
     const float m0 = vmax3(vmax3(mx[0][0], mx[0][1], mx[0][2]), mx[0][3], mx[0][3]) - t1q[0];
     const float m1 = vmax3(vmax3(mx[1][0], mx[1][1], mx[1][2]), mx[1][3], mx[1][3]) - t1q[1];
-    return __builtin_amdgcn_ballot_w64(vmax3(m0, m1, m1) >= 0.f) != 0;
+    flagv = vmax3(m0, m1, m1);
   };
+  auto any_flag = [&]() -> bool { return __builtin_amdgcn_ballot_w64(flagv >= 0.f) != 0; };
   // rare path of one tested block: `a` its accumulators, `stage` / `row0` its tile, mb its row block.  Returns the number of
   // deferred loads it issued.  Per query block: the flagged group(s) of 4 registers -> the flagged values -> one slot each;
   // a block with more flagged values than free slots gives its slots back and takes the lo-plane MFMAs instead.
   auto rare_path = [&](const intx16 (&a)[NB], const char* stage, uint32_t row0, int mb) -> uint32_t {
     ++n_stage1;
     uint32_t issued = 0;
+    if constexpr (VAR == 4) return issued;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const uint32_t before = pend_mask;
@@ -1706,7 +1724,8 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     // Behind every MFMA at most one value of the other block's test (slots W0 .. W0 + 31 of the half's 2 KSTEPS MFMAs:
     // <= 3 VALU instructions inside the MFMA's 24 free issue cycles).  The A-fragment ring is primed per half: keeping it
     // alive across the rare path between the halves costs more registers than the file has.
-    constexpr int NSLOT = 2 * KSTEPS, W0 = NSLOT / 4 < 8 ? NSLOT / 4 : 8, VPS = (32 + NSLOT - W0 - 1) / (NSLOT - W0);   // values per slot: 1 at d = 768
+    constexpr int NSLOT = 2 * KSTEPS, W0 = NSLOT / 4 < 8 ? NSLOT / 4 : 8, VPS = (32 + NSLOT - W0 - 4) / (NSLOT - W0 - 3);   // values per slot: 1 at d = 768
+    static_assert(VPS >= 1 && W0 + (32 + VPS - 1) / VPS + 1 <= NSLOT - 2 && (VPS == 1 || VPS % 2 == 0), "the three test stages end before the half's last MFMA");
     // ---- first half: block 0 of tile t  ||  test of block 1 of tile t-1 (t == 0: garbage, tested and ignored) ----------
     load_scales(prev_stage, 1);
     reset_max();
@@ -1721,14 +1740,14 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
         if (s == 0) NVDB_MFMA_I8_ZERO(acc0[nb], av, bq[nb * KSTEPS]);
         else NVDB_MFMA_I8_ACC(acc0[nb], av, bq[nb * KSTEPS + s]);
         const int w = 2 * s + nb;
-#pragma unroll
-        for (int v = (w - W0) * VPS; v < (w - W0 + 1) * VPS; ++v) if (w >= W0 && v < 32) test_value(acc1, v);
+        test_step(acc1, w - W0, VPS);
+        if (w == NSLOT - 1) combine_flags();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     young_loads = 0;
-    if (VAR == 0 && t > 0 && any_flag()) young_loads = rare_path(acc1, prev_stage, tile_row0(t - 1), 1);
-    if constexpr (VAR != 0) { asm volatile("" ::"v"(mx[0][0]), "v"(mx[1][0]), "v"(mx[0][1]), "v"(mx[1][1]), "v"(mx[0][2]), "v"(mx[1][2]), "v"(mx[0][3]), "v"(mx[1][3])); }   // keep this half's test alive
+    if ((VAR == 0 || VAR >= 3) && t > 0 && any_flag()) young_loads = rare_path(acc1, prev_stage, tile_row0(t - 1), 1);
+    if constexpr (VAR == 1 || VAR == 2) { asm volatile("" ::"v"(flagv)); }   // keep this half's test alive
     __builtin_amdgcn_s_barrier();                                          // B: nobody reads the stage of tile t-1 any more
     // ---- second half: block 1 of tile t  ||  loads of tile t+2, test of block 0 of tile t ---------------------------
     load_scales(stage, 0);
@@ -1744,8 +1763,8 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
         if (s == 0) NVDB_MFMA_I8_ZERO(acc1[nb], av, bq[nb * KSTEPS]);
         else NVDB_MFMA_I8_ACC(acc1[nb], av, bq[nb * KSTEPS + s]);
         const int w = 2 * s + nb;
-#pragma unroll
-        for (int v = (w - W0) * VPS; v < (w - W0 + 1) * VPS; ++v) if (w >= W0 && v < 32) test_value(acc0, v);
+        test_step(acc0, w - W0, VPS);
+        if (w == NSLOT - 1) combine_flags();
         __builtin_amdgcn_sched_barrier(0);
       }
       if (s % (KSTEPS / PPW) == KSTEPS / PPW - 1) issue_piece(next_row0, next_buf, s / (KSTEPS / PPW));
@@ -1754,9 +1773,9 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     }
     // what was deferred during the PREVIOUS tile is at least one tile old now; behind it: this tile's deferred loads and its PPW + 1 pieces
     if (pend_old) consume_slots(pend_old, PPW + 1 + young_loads);
-    if (VAR == 0 && any_flag()) rare_path(acc0, stage, tile_row0(t), 0);
+    if ((VAR == 0 || VAR >= 3) && any_flag()) rare_path(acc0, stage, tile_row0(t), 0);
     pend_old = pend_mask;                                                  // everything deferred during this tile: due at the end of the next
-    if constexpr (VAR != 0) { asm volatile("" ::"v"(mx[0][0]), "v"(mx[1][0]), "v"(mx[0][1]), "v"(mx[1][1]), "v"(mx[0][2]), "v"(mx[1][2]), "v"(mx[0][3]), "v"(mx[1][3])); }
+    if constexpr (VAR == 1 || VAR == 2) { asm volatile("" ::"v"(flagv)); }
   }
   if (wave_has_queries) {                          // block 1 of the last tile
     const char* last_stage = smem + ((NT - 1) % NSTAGE) * STAGE_BYTES;
@@ -1764,9 +1783,10 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     load_scales(last_stage, 1);
     reset_max();
 #pragma unroll
-    for (int v = 0; v < 32; ++v) test_value(acc1, v);
+    for (int j = 0; j < 34; ++j) test_step(acc1, j, 1);
+    combine_flags();
     if (pend_mask) consume_slots(pend_mask, 0);
-    if (VAR == 0 && any_flag()) rare_path(acc1, last_stage, tile_row0(NT - 1), 1);
+    if ((VAR == 0 || VAR >= 3) && any_flag()) rare_path(acc1, last_stage, tile_row0(NT - 1), 1);
     if (pend_mask) consume_slots(pend_mask, 0);
   }
   if constexpr (STAMP) {

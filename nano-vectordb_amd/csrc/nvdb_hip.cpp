@@ -1548,6 +1548,8 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
       case 10: NVDB_CLK_I8P(0) break;             // the software-pipelined production build, stamped
       case 11: NVDB_CLK_I8P(1) break;             // ... its structure alone: no test, no rare path
       case 12: NVDB_CLK_I8P(2) break;             // ... test in the MFMA shadow, rare path never taken
+      case 13: NVDB_CLK_I8P(3) break;             // ... rare path, deferred values never consumed
+      case 14: NVDB_CLK_I8P(4) break;             // ... rare path entered and left at once
       default: return fail(c, NVDB_ERR_INVALID, "debug: unknown variant");
     }
     HIPCHK(c, hipGetLastError());
