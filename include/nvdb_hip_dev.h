@@ -23,9 +23,16 @@ nvdb_status nvdb_hip_debug_filter_variant(nvdb_hip_ctx* ctx, int variant, uint32
 /* Developer aid: the clock the chip holds inside the production fp16 d=768 filter kernel.  Launches a diagnostic
  * build (identical code + one s_memtime / s_memrealtime stamp pair around the tile loop of every workgroup) back to
  * back for `seconds`, then reports out4 = { ms per launch (last 8), median, min, max over workgroups of
- * delta(s_memtime) / delta(s_memrealtime) x 100 MHz in GHz }.  variant: 0 = the production loop; timing-only
+ * delta(s_memtime) / delta(s_memrealtime) x 100 MHz in GHz, mean and max over workgroups of the tile loop's duration in us, then per XCD label (blockIdx % 8) the mean duration and its spread } (22 floats).  variant: 0 = the production loop; timing-only
  * ablations 1 = no direct-to-LDS loads, 5 = no LDS reads, 15 = neither.  Same preconditions as the call above. */
 nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* ctx, int variant, uint32_t nq, float seconds, float* out4);
+
+/* The tile range [lo, hi) the device's XCD-balanced partition (kernels_filter.h stream_tile_range) gives each of n_streams
+ * row streams over n_tiles tiles, evaluated ON the device with weights8 (8 floats; NULL = the context's current, adapted
+ * weights, which are also returned in weights_out8 if that is non-NULL).  tests/test_gpu_parity.py checks that the ranges tile
+ * [0, n_tiles) exactly for any weights. */
+nvdb_status nvdb_hip_debug_tile_ranges(nvdb_hip_ctx* ctx, uint32_t n_tiles, uint32_t n_streams, const float* weights8, uint32_t* out_lo,
+                                       uint32_t* out_hi, float* weights_out8);
 
 /* Developer aid (host only, no GPU): the physical tile the filter kernels stream for logical tile g of a corpus of n_tiles
  * tiles -- a bijection of [0, n_tiles) (identity below 64 tiles).  tests/test_cabi_cpu.py checks that property. */

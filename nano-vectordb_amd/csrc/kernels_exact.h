@@ -303,11 +303,38 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(
 __global__ __launch_bounds__(256) void select_kernel(
     Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t k, const float* __restrict__ slack,
     float* __restrict__ thr, uint32_t* __restrict__ overflow, int mode, uint64_t row_base,
-    unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, uint32_t out_k, uint32_t* __restrict__ any_overflow) {
+    unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, uint32_t out_k, uint32_t* __restrict__ any_overflow,
+    float* __restrict__ xcdw) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Cand* e = reinterpret_cast<Cand*>(smem_raw);
   __shared__ uint32_t s_keep;
   const uint32_t q = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+  // XCD balance (kernels_filter.h, ScatterArgs::xcdw): the filter launch before this kernel filed tile-loop time and tile
+  // counts per XCD label; turn them into the relative speeds the next launch partitions its tiles by.  Half-way steps,
+  // a +-10 % cage and renormalisation to mean 1 keep one odd launch from skewing the shares.
+  if (xcdw != nullptr && q == 0 && tid == 0) {
+    float sp[8], mean = 0.f;
+    bool all = true;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const float us = xcdw[8 + x], tiles = xcdw[16 + x];
+      all = all && us > 0.f && tiles > 0.f;
+      sp[x] = tiles / fmaxf(us, 1e-3f);
+      mean += sp[x] * 0.125f;
+    }
+    if (all) {
+      float w[8], wsum = 0.f;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        w[x] = fminf(fmaxf(0.5f * xcdw[x] + 0.5f * sp[x] / mean, 0.9f), 1.1f);     // tiles per microsecond is the XCD's own speed, whatever share it ran with
+        wsum += w[x];
+      }
+#pragma unroll
+      for (int x = 0; x < 8; ++x) xcdw[x] = w[x] * (8.f / wsum);
+    }
+#pragma unroll
+    for (int x = 8; x < 24; ++x) xcdw[x] = 0.f;
+  }
   uint32_t m = (mode == 2) ? out_k : cnt[q];     // mode 2 (bootstrap): every list holds exactly out_k tile maxima
   if (m > cap) { if (tid == 0) overflow[q] = 1u; m = cap; }
   // final select: fold the per-query flags (list overflow, non-finite query) into one word the host can read alone,

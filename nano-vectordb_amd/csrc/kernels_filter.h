@@ -150,7 +150,46 @@ struct ScatterArgs {
   // multiplier modulo the next power of two, cycle-walked back into [0, perm_T) -- a bijection of the corpus' tiles
   // that costs a handful of scalar instructions per tile.  perm_mask == 0: identity.
   uint32_t perm_mul, perm_mask, perm_T;
+  // XCD balance (null: equal shares).  The chip's 8 XCDs do not run at the same speed under this load (their tile loops differ by
+  // +-3.5 %, workgroups inside one XCD by 0.3 %: profiles/r02_xcd_balance_clock.txt) and a launch ends with its slowest workgroup.
+  // xcdw[0..7]: relative speed of XCD label x (mean 1) -- the row streams of label x get a share of the tiles proportional to it;
+  // xcdw[8..15], [16..23]: tile-loop microseconds and tiles per label, added up by the big launches, turned into new weights by
+  // the select kernel that follows every filter launch (device-side only, nothing for the host to read).
+  float* xcdw;
 };
+
+// tiles [lo, hi) of row stream `stream` out of S streams over T tiles.  Streams s with equal s & 7 share an XCD label when the
+// XCD-aware block mapping is active (xcd_map); f(s) is the same monotone expression for every workgroup, f(0) = 0, f(S) = T.
+__device__ __forceinline__ void stream_tile_range(uint32_t T, uint32_t S, uint32_t stream, bool xcd_map, const float* xcdw, uint32_t& lo, uint32_t& hi) {
+  if (!xcd_map || xcdw == nullptr || (S & 7u) != 0) {
+    lo = static_cast<uint32_t>(static_cast<uint64_t>(T) * stream / S);
+    hi = static_cast<uint32_t>(static_cast<uint64_t>(T) * (stream + 1) / S);
+    return;
+  }
+  double pre[9];
+  pre[0] = 0.0;
+#pragma unroll
+  for (int x = 0; x < 8; ++x) pre[x + 1] = pre[x] + static_cast<double>(xcdw[x]);
+  const double total = pre[8] * static_cast<double>(S >> 3);
+  auto f = [&](uint32_t s) -> uint32_t {
+    if (s >= S) return T;
+    double part = 0.0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) part = (static_cast<uint32_t>(x) == (s & 7u)) ? pre[x] : part;
+    const double cum = pre[8] * static_cast<double>(s >> 3) + part;
+    const uint32_t v = static_cast<uint32_t>(static_cast<double>(T) * (cum / total));
+    return v > T ? T : v;
+  };
+  lo = f(stream);
+  hi = f(stream + 1);
+}
+
+// end of a big launch: this workgroup's tile-loop time and tile count, filed under its XCD label
+__device__ __forceinline__ void record_xcd_speed(float* xcdw, bool xcd_map, uint32_t label, uint32_t ntiles, uint32_t ticks_100mhz) {
+  if (xcdw == nullptr || !xcd_map || ntiles < 128) return;
+  atomicAdd(xcdw + 8 + label, static_cast<float>(ticks_100mhz) * 0.01f);
+  atomicAdd(xcdw + 16 + label, static_cast<float>(ntiles));
+}
 
 __host__ __device__ __forceinline__ uint32_t perm_tile_raw(uint32_t g, uint32_t mul, uint32_t mask, uint32_t T) {
   if (mask == 0) return g;
@@ -239,8 +278,9 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
     stream = (i / QT) * 8u + xcd;
   } else { qt = b % QT; stream = b / QT; }
   const uint32_t tiles_total = (row_hi - row_lo) / FILTER_ROWS;
-  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
-  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const bool xcd_map = (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+  uint32_t t_lo, t_hi;
+  stream_tile_range(tiles_total, S, stream, xcd_map, sa.xcdw, t_lo, t_hi);
   const uint32_t NT = t_hi - t_lo;
   if (NT == 0) return;
 
@@ -316,6 +356,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
   uint32_t wcnt = 0;                               // survivors logged by this wave (uniform)
   Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
 
+  const uint32_t xw_t0 = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
   for (uint32_t t = 0; t < NT; ++t) {
     // my pieces of tile t have landed once all but the newest stage's PPW loads are complete
     if constexpr (VAR != 1 && VAR != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
@@ -439,6 +480,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_kernel(
       }
     }
   }
+  if (wave == 0 && lane == 0) record_xcd_speed(sa.xcdw, xcd_map, stream & 7u, NT, static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) - xw_t0);
   if constexpr (VAR == 0) scatter_own_log(mylog, wcnt, sa, lane);
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two speculative stages before exit
 }
@@ -520,8 +562,9 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_f16_m16_kernel(
   if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
   else { qt = b % QT; stream = b / QT; }
   const uint32_t tiles_total = (row_hi - row_lo) / TROWS;
-  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
-  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const bool xcd_map = (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+  uint32_t t_lo, t_hi;
+  stream_tile_range(tiles_total, S, stream, xcd_map, sa.xcdw, t_lo, t_hi);
   const uint32_t NT = t_hi - t_lo;
   if (NT == 0) return;
 
@@ -587,6 +630,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_f16_m16_kernel(
   uint32_t sync_strikes = 0;                       // rendezvous that timed out; after 3 this workgroup stops waiting
   uint64_t stamp_c = 0, stamp_r = 0;
   if constexpr (STAMP) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
+  const uint32_t xw_t0 = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
       // wave 0 only; the per-tile barrier holds the other waves back
@@ -686,6 +730,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_f16_m16_kernel(
     }
   }
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(myprog + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (wave == 0 && lane == 0) record_xcd_speed(sa.xcdw, xcd_map, stream & 7u, NT, static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) - xw_t0);
   scatter_own_log(mylog, wcnt, sa, lane);
 }
 
@@ -724,8 +769,9 @@ __global__ __launch_bounds__(256, 1) void filter_f16_k2_kernel(
   if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
   else { qt = b % QT; stream = b / QT; }
   const uint32_t tiles_total = (row_hi - row_lo) / TROWS;
-  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
-  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const bool xcd_map = (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+  uint32_t t_lo, t_hi;
+  stream_tile_range(tiles_total, S, stream, xcd_map, sa.xcdw, t_lo, t_hi);
   const uint32_t NT = t_hi - t_lo;
   if (NT == 0) return;
 
@@ -778,6 +824,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_k2_kernel(
   Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
   uint32_t* myprog = prog + static_cast<uint64_t>(stream) * 8;
   uint32_t sync_strikes = 0;
+  const uint32_t xw_t0 = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
       if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(myprog, qt, t, sync_lead, sync_strikes, lane);
@@ -832,6 +879,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_k2_kernel(
     }
   }
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(myprog + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (wave == 0 && lane == 0) record_xcd_speed(sa.xcdw, xcd_map, stream & 7u, NT, static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) - xw_t0);
   scatter_own_log(mylog, wcnt, sa, lane);
 }
 
@@ -932,8 +980,9 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
   if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
   else { qt = b % QT; stream = b / QT; }
   const uint32_t tiles_total = (row_hi - row_lo) / FILTER_ROWS;
-  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
-  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const bool xcd_map = (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+  uint32_t t_lo, t_hi;
+  stream_tile_range(tiles_total, S, stream, xcd_map, sa.xcdw, t_lo, t_hi);
   const uint32_t NT = t_hi - t_lo;
   if (NT == 0) return;
 
@@ -988,6 +1037,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
   Hit* mylog = hitlog + static_cast<uint64_t>(wave_gid) * FILTER_LOGCAP;
 
   uint32_t sync_strikes = 0;
+  const uint32_t xw_t0 = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
       if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(prog + static_cast<uint64_t>(stream) * 8, qt, t, sync_lead, sync_strikes, lane);
@@ -1077,6 +1127,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
     }
   }
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(prog + static_cast<uint64_t>(stream) * 8 + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (wave == 0 && lane == 0) record_xcd_speed(sa.xcdw, xcd_map, stream & 7u, NT, static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) - xw_t0);
   if constexpr (!BOOT) scatter_own_log(mylog, wcnt, sa, lane);
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1149,8 +1200,9 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
   else { qt = b % QT; stream = b / QT; }
   const uint32_t tiles_total = (row_hi - row_lo) / TROWS;
-  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
-  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const bool xcd_map = (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+  uint32_t t_lo, t_hi;
+  stream_tile_range(tiles_total, S, stream, xcd_map, sa.xcdw, t_lo, t_hi);
   const uint32_t NT = t_hi - t_lo;
   if (NT == 0) return;
 
@@ -1250,6 +1302,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   uint32_t sync_strikes = 0;
   uint64_t stamp_c = 0, stamp_r = 0;
   if constexpr (STAMP) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
+  const uint32_t xw_t0 = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
       if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(prog + static_cast<uint64_t>(stream) * 8, qt, t, sync_lead, sync_strikes, lane);
@@ -1407,6 +1460,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   }
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(prog + static_cast<uint64_t>(stream) * 8 + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (stage_counts && lane == 0 && (n_stage1 | n_stage2)) { atomicAdd(stage_counts, n_stage1); atomicAdd(stage_counts + 1, n_stage2); }
+  if (wave == 0 && lane == 0) record_xcd_speed(sa.xcdw, xcd_map, stream & 7u, NT, static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) - xw_t0);
   scatter_own_log(mylog, wcnt, sa, lane);
 }
 
@@ -1462,8 +1516,9 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   if ((nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0) { const uint32_t xcd = b & 7u, i = b >> 3; qt = i % QT; stream = (i / QT) * 8u + xcd; }
   else { qt = b % QT; stream = b / QT; }
   const uint32_t tiles_total = (row_hi - row_lo) / TROWS;
-  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * stream / S);
-  const uint32_t t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles_total) * (stream + 1) / S);
+  const bool xcd_map = (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+  uint32_t t_lo, t_hi;
+  stream_tile_range(tiles_total, S, stream, xcd_map, sa.xcdw, t_lo, t_hi);
   const uint32_t NT = t_hi - t_lo;
   if (NT == 0) return;
 
@@ -1705,6 +1760,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   uint32_t sync_strikes = 0;
   uint64_t stamp_c = 0, stamp_r = 0;
   if constexpr (STAMP) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
+  const uint32_t xw_t0 = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
       if (wave == 0 && (t & sync_mask) == 0) sibling_rendezvous(prog + static_cast<uint64_t>(stream) * 8, qt, t, sync_lead, sync_strikes, lane);
@@ -1798,6 +1854,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   }
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(prog + static_cast<uint64_t>(stream) * 8 + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (stage_counts && lane == 0 && (n_stage1 | n_stage2)) { atomicAdd(stage_counts, n_stage1); atomicAdd(stage_counts + 1, n_stage2); }
+  if (wave == 0 && lane == 0) record_xcd_speed(sa.xcdw, xcd_map, stream & 7u, NT, static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) - xw_t0);
   scatter_own_log(mylog, wcnt, sa, lane);
 }
 

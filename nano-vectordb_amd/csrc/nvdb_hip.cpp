@@ -85,6 +85,8 @@ struct nvdb_hip_ctx {
   // grow-only workspace
   DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, prog;
   DevBuf rq, rcand, rout_ids, rout_dist;           // refine
+  DevBuf xcdw;                                     // XCD balance: 8 speed weights + 16 accumulators (kernels_filter.h ScatterArgs::xcdw)
+  int64_t opt_xcd_balance = 1;
   DevBuf lk_scores, lk_sel, lk_hist, lk_state;     // any-k path (kernels_largek.h): score matrix of a query sub-batch, selected keys, radix state
   int64_t opt_refine_pinned = 0;                   // refine host call: stage queries / candidates / results through pinned host buffers (reference CUDA_PINNED)
   void* rpinned = nullptr;                         // ... [queries | candidates | out ids | out dist]
@@ -292,7 +294,8 @@ nvdb_status launch_select(nvdb_hip_ctx* c, hipStream_t s, uint32_t nq, uint32_t 
   select_kernel<<<nq, 256, cap2 * sizeof(Cand), s>>>(static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap, k, slack,
                                                    static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->overflow.p), mode,
                                                    c->row_base, reinterpret_cast<unsigned long long*>(out_ids), out_scores, out_k,
-                                                   static_cast<uint32_t*>(c->misc.p) + 6);
+                                                   static_cast<uint32_t*>(c->misc.p) + 6,
+                                                   c->opt_xcd_balance ? static_cast<float*>(c->xcdw.p) : nullptr);
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -348,7 +351,8 @@ nvdb_status next_prog_region(nvdb_hip_ctx* c, hipStream_t s, uint32_t nwg, uint3
 // of the corpus' T = ceil-or-floor(n / trows) tiles is streamed from physical tile perm_tile(g) (kernels_filter.h).
 ScatterArgs scatter_args(nvdb_hip_ctx* c, uint32_t cap, uint32_t trows = 0) {
   ScatterArgs a{static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), static_cast<uint32_t*>(c->overflow.p),
-                static_cast<uint32_t*>(c->misc.p) + 1, cap, static_cast<uint32_t>(c->n), 1u, 0u, 0u};
+                static_cast<uint32_t*>(c->misc.p) + 1, cap, static_cast<uint32_t>(c->n), 1u, 0u, 0u,
+                c->opt_xcd_balance ? static_cast<float*>(c->xcdw.p) : nullptr};
   if (trows && c->perm_on) {
     const bool padded = c->owned || c->shadow16 != nullptr || c->shadow8 != nullptr;
     const uint32_t n = static_cast<uint32_t>(c->n);
@@ -965,6 +969,18 @@ nvdb_status nvdb_hip_create(int device_ordinal, nvdb_hip_ctx** out_ctx) {
     delete c;
     return NVDB_ERR_HIP;
   }
+  {
+    float w0[24];
+    for (int i = 0; i < 24; ++i) w0[i] = i < 8 ? 1.f : 0.f;
+    if ((e = hipMalloc(&c->xcdw.p, sizeof(w0))) != hipSuccess || (e = hipMemcpy(c->xcdw.p, w0, sizeof(w0), hipMemcpyHostToDevice)) != hipSuccess) {
+      g_create_err = hipGetErrorString(e);
+      if (c->xcdw.p) (void)hipFree(c->xcdw.p);
+      (void)hipStreamDestroy(c->stream);
+      delete c;
+      return NVDB_ERR_HIP;
+    }
+    c->xcdw.bytes = sizeof(w0);
+  }
   *out_ctx = c;
   return NVDB_OK;
 }
@@ -975,7 +991,7 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   free_corpus(c);
   for (DevBuf* b : {&c->q32, &c->q16, &c->qscale, &c->qinv, &c->ebound, &c->slack, &c->thr, &c->cnt, &c->overflow, &c->cand,
-                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->prog, &c->qdelta, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist, &c->lk_scores, &c->lk_sel, &c->lk_hist, &c->lk_state})
+                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->prog, &c->qdelta, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist, &c->lk_scores, &c->lk_sel, &c->lk_hist, &c->lk_state, &c->xcdw})
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& k : c->klaunch) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
@@ -1094,6 +1110,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "f32_shadow") { c->opt_f32_shadow = value ? 1 : 0; }
   else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }
   else if (k == "i8_pipe") { c->opt_i8_pipe = value ? 1 : 0; }
+  else if (k == "xcd_balance") { c->opt_xcd_balance = value ? 1 : 0; }
   else if (k == "waves8") { c->opt_waves8 = value ? 1 : 0; }
   else if (k == "tile_permute") { c->opt_tile_permute = value ? 1 : 0; }
   else if (k == "rescore8") { c->opt_rescore8 = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -1483,6 +1500,18 @@ nvdb_status nvdb_hip_debug_clock(nvdb_hip_ctx* c, int variant, uint32_t nq, floa
   out4[1] = ghz.empty() ? 0.f : ghz[ghz.size() / 2];
   out4[2] = ghz.empty() ? 0.f : ghz.front();
   out4[3] = ghz.empty() ? 0.f : ghz.back();
+  // how long the workgroups' tile loops ran (100 MHz ticks -> us): mean and max -- the launch ends with the slowest
+  double sum_us = 0.0, max_us = 0.0;
+  for (uint32_t w = 0; w < nwg; ++w) { const double us = static_cast<double>(stamps[2 * w + 1]) * 0.01; sum_us += us; max_us = std::max(max_us, us); }
+  out4[4] = static_cast<float>(sum_us / nwg);
+  out4[5] = static_cast<float>(max_us);
+  // per XCD label (blockIdx % 8): mean duration, and the spread inside the label (max - min)
+  for (uint32_t x = 0; x < 8; ++x) {
+    double sx = 0.0, mn = 1e30, mxv = 0.0; uint32_t cnt = 0;
+    for (uint32_t w = x; w < nwg; w += 8) { const double us = static_cast<double>(stamps[2 * w + 1]) * 0.01; sx += us; mn = std::min(mn, us); mxv = std::max(mxv, us); ++cnt; }
+    out4[6 + 2 * x] = cnt ? static_cast<float>(sx / cnt) : 0.f;
+    out4[7 + 2 * x] = cnt ? static_cast<float>(mxv - mn) : 0.f;
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(inf.p);
   return NVDB_OK;
@@ -1579,6 +1608,35 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
   out4[4] = static_cast<float>(counts[0]) / burst;
   out4[5] = static_cast<float>(counts[1]) / burst;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return NVDB_OK;
+}
+
+// the device's own stream_tile_range for every stream of a launch, with the weights given (or the context's current ones)
+__global__ void tile_ranges_kernel(uint32_t T, uint32_t S, const float* w, uint32_t* lo, uint32_t* hi) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < S) stream_tile_range(T, S, s, true, w, lo[s], hi[s]);
+}
+
+nvdb_status nvdb_hip_debug_tile_ranges(nvdb_hip_ctx* c, uint32_t n_tiles, uint32_t n_streams, const float* weights8, uint32_t* out_lo, uint32_t* out_hi,
+                                       float* weights_out8) {
+  if (!c || !n_streams || !out_lo || !out_hi) return c ? fail(c, NVDB_ERR_INVALID, "bad argument") : NVDB_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf buf;
+  nvdb_status st;
+  if ((st = ensure(c, buf, static_cast<size_t>(n_streams) * 8 + 32))) return st;
+  uint32_t* lo = static_cast<uint32_t*>(buf.p);
+  uint32_t* hi = lo + n_streams;
+  float* w = reinterpret_cast<float*>(hi + n_streams);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (weights8) HIPCHK(c, hipMemcpy(w, weights8, 32, hipMemcpyHostToDevice));
+  else HIPCHK(c, hipMemcpy(w, c->xcdw.p, 32, hipMemcpyDeviceToDevice));
+  tile_ranges_kernel<<<(n_streams + 255) / 256, 256, 0, c->stream>>>(n_tiles, n_streams, w, lo, hi);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out_lo, lo, static_cast<size_t>(n_streams) * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(out_hi, hi, static_cast<size_t>(n_streams) * 4, hipMemcpyDeviceToHost));
+  if (weights_out8) HIPCHK(c, hipMemcpy(weights_out8, w, 32, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipFree(buf.p));
   return NVDB_OK;
 }
 #endif  // NVDB_HIP_DEV

@@ -30,7 +30,7 @@ EXPORTS = [
     "nvdb_quantize_i8_rows",
 ]
 # only in libnvdb_hip_dev.so; the product library must NOT export them (tests/test_cabi_cpu.py)
-DEV_EXPORTS = ["nvdb_hip_debug_filter_variant", "nvdb_hip_debug_clock", "nvdb_hip_debug_clock_i8", "nvdb_permuted_tile"]
+DEV_EXPORTS = ["nvdb_hip_debug_filter_variant", "nvdb_hip_debug_clock", "nvdb_hip_debug_clock_i8", "nvdb_permuted_tile", "nvdb_hip_debug_tile_ranges"]
 
 
 class NvdbError(RuntimeError):
@@ -116,6 +116,7 @@ def _bind(L, dev):
         L.nvdb_hip_debug_clock.argtypes = [vp, C.c_int, u32, C.c_float, f32p]
         L.nvdb_hip_debug_clock_i8.argtypes = [vp, C.c_int, u32, C.c_float, f32p]
         L.nvdb_permuted_tile.argtypes = [u32, u32]
+        L.nvdb_hip_debug_tile_ranges.argtypes = [vp, u32, u32, f32p, C.POINTER(u32), C.POINTER(u32), f32p]
         L.nvdb_permuted_tile.restype = u32
     return L
 

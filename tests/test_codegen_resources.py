@@ -61,7 +61,8 @@ def test_no_kernel_uses_scratch_or_spills(codegen):
     assert not bad, bad
     # SGPRs parked in VGPR lanes cost nothing in memory; only the exact fp32 kernels at 8 queries per group do it
     parked = {k for k, v in by_name.items() if v["sspill"]}
-    assert all(k.startswith(("scan_exact_kernel<", "filter_i8p_kernel<")) for k in parked), parked      # i8p: the 4-slot deferred queue is uniform state
+    # i8p: the 4-slot deferred queue is uniform state; i8w (the A/B alternative, not the default): the XCD-balance stamp and label
+    assert all(k.startswith(("scan_exact_kernel<", "filter_i8p_kernel<", "filter_i8w_kernel<")) for k in parked), parked
 
 
 def test_register_budgets_of_the_production_kernels(codegen):
@@ -93,9 +94,9 @@ def test_rendezvous_registers_and_hand_placed_instructions(codegen):
             n_sync += 1
             assert v["sgpr"] >= 96, (key, v)                             # s88..s95 are inside the kernel's allocation
             # the block is intact: the load, its wait, then the eight moves out of s88..s95 (nothing in between)
-            for blk in re.finditer(r"s_load_dwordx8 s\[88:95\][^\n]*\n\s*s_waitcnt lgkmcnt\(0\)\n((?:\s*s_mov_b32 s\d+, s(?:8[89]|9[0-5])\n){8})", body):
+            for blk in re.finditer(r"s_load_dwordx8 s\[88:95\][^\n]*\n\s*s_waitcnt lgkmcnt\(0\)\n((?:\s*s_mov_b32 (?:s\d+|vcc_lo|vcc_hi), s(?:8[89]|9[0-5])\n){8})", body):
                 assert sorted(re.findall(r", s(\d+)\n", blk.group(1))) == [str(x) for x in range(88, 96)]
-            assert len(re.findall(r"s_load_dwordx8 s\[88:95\]", body)) == len(re.findall(r"s_load_dwordx8 s\[88:95\][^\n]*\n\s*s_waitcnt lgkmcnt\(0\)\n(?:\s*s_mov_b32 s\d+, s(?:8[89]|9[0-5])\n){8}", body))
+            assert len(re.findall(r"s_load_dwordx8 s\[88:95\]", body)) == len(re.findall(r"s_load_dwordx8 s\[88:95\][^\n]*\n\s*s_waitcnt lgkmcnt\(0\)\n(?:\s*s_mov_b32 (?:s\d+|vcc_lo|vcc_hi), s(?:8[89]|9[0-5])\n){8}", body))
     assert n_sync >= 8
     # the compiler keeps nothing live in s88..s95 across the block because the asm statement declares them clobbered
     src = open(os.path.join(PKG, "csrc", "kernels_filter.h")).read()

@@ -705,6 +705,54 @@ def test_full_size_10M_properties(oracle, dtype, tag):
     assert np.array_equal(mi, ids) and np.array_equal(ms.view(np.uint32), sc.view(np.uint32))
 
 
+def test_xcd_balanced_partition_tiles_the_corpus_and_leaves_results_unchanged(oracle):
+    """The persistent filter kernels give the row streams of XCD label x a share of the tiles proportional to that XCD's
+    measured speed (kernels_filter.h stream_tile_range / record_xcd_speed; weights adapted by select_kernel).
+      (1) the device's partition function tiles [0, T) exactly -- no tile skipped, none visited twice -- for any weights
+          in the cage, any T and any stream count (developer library: the function itself, evaluated on the GPU);
+      (2) searches with the balance off, on, and on again after the weights have adapted return identical bits;
+      (3) the adapted weights stay inside the cage and average 1."""
+    import ctypes as C
+    c = nvdb_amd.HipContext(0, dev=True)
+    u32p, f32p = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+
+    def ranges(T, S, w):
+        lo, hi, wout = np.empty(S, np.uint32), np.empty(S, np.uint32), np.empty(8, np.float32)
+        st = c.lib.nvdb_hip_debug_tile_ranges(c.h, T, S, w.ctypes.data_as(f32p) if w is not None else None,
+                                              lo.ctypes.data_as(u32p), hi.ctypes.data_as(u32p), wout.ctypes.data_as(f32p))
+        assert st == 0, c.lib.nvdb_hip_last_error(c.h)
+        return lo.astype(np.int64), hi.astype(np.int64), wout
+    rs = np.random.RandomState(5)
+    for T, S in ((78125, 64), (781250, 256), (4883, 256), (300, 64), (7, 8), (1_000_003, 512), (0, 8), (4_294_967, 8), (12345, 24), (999, 12)):
+        for trial in range(5):
+            w = np.ones(8, np.float32) if trial == 0 else rs.uniform(0.9, 1.1, 8).astype(np.float32)
+            if trial == 4:
+                w = np.array([0.9, 1.1] * 4, np.float32)
+            lo, hi, _ = ranges(T, S, w)
+            assert lo[0] == 0 and hi[-1] == T and np.array_equal(lo[1:], hi[:-1]) and np.all(hi >= lo), (T, S, trial)
+            if trial == 0 or S % 8:                                  # equal weights (or no XCD labels): the plain equal split, give or take a rounding
+                assert np.all(np.abs(lo - (T * np.arange(S, dtype=np.int64)) // S) <= 1), (T, S)
+            elif T >= 64 * S:                                        # shares follow the weights
+                per = (hi - lo).reshape(-1, 8).sum(axis=0).astype(np.float64)
+                assert np.allclose(per / per.sum(), w.astype(np.float64) / w.astype(np.float64).sum(), atol=2e-3), (T, S, trial)
+    n, d, nq, k = 2_000_000, 768, 1024, 10
+    queries = nvdb_amd.synth_rows_f32(SEED + 1, 0, nq, d)
+    for dtype in (nvdb_amd.DT_F16, nvdb_amd.DT_I8):
+        c.generate_corpus(SEED, n, d, dtype)
+        c.set_option("xcd_balance", 0)
+        ids0, sc0 = c.search_batch(queries, k)
+        assert c.stats()["path"] == 2
+        c.set_option("xcd_balance", 1)
+        for rep in range(4):
+            ids, sc = c.search_batch(queries, k)
+            st = c.stats()
+            assert st["path"] == 2 and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+            assert np.array_equal(ids, ids0) and np.array_equal(sc.view(np.uint32), sc0.view(np.uint32)), (dtype, rep)
+        _, _, w = ranges(1000, 64, None)
+        assert np.all(w >= 0.88) and np.all(w <= 1.12) and abs(float(w.mean()) - 1.0) < 1e-3, w
+    c.close()
+
+
 def _rescore_returned_rows(oracle, ctx, queries, ids, sc, d, every):
     """(a) of the full-size properties: every `every`-th query's returned scores are, bit for bit, the reference CPU
     score (oracle dot, simd_dot.cpp:102-124) of the returned rows copied back from HBM."""
