@@ -42,7 +42,8 @@ uint32_t nvdb_permuted_tile(uint32_t g, uint32_t n_tiles);
  * production loop (variant 0) and of its timing-only ablations 1 = no stage 2 (the lo-plane pass never runs),
  * 2 = no stage-1 test either (stream + hi-plane MFMAs only), 3 = 2 + no per-tile barrier; 10 = the software-pipelined build
  * (filter_i8p_kernel), 11 = its structure alone, 12 = test without rare path.  out[0..3] as above, out[4], out[5] = rare-path
- * entries and lo-plane MFMA blocks per launch (out must hold 6 floats). */
+ * entries and lo-plane MFMA blocks per launch, out[6], out[7] = mean and longest tile-loop duration of a workgroup in us (out must hold 8 floats).
+ * Developer option "debug_rows" (nvdb_hip_set_option, this build only): the launches cover rows [0, debug_rows) instead of the corpus. */
 nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* ctx, int variant, uint32_t nq, float seconds, float* out4);
 
 #ifdef __cplusplus

@@ -156,6 +156,9 @@ struct ScatterArgs {
   // xcdw[8..15], [16..23]: tile-loop microseconds and tiles per label, added up by the big launches, turned into new weights by
   // the select kernel that follows every filter launch (device-side only, nothing for the host to read).
   float* xcdw;
+  // int8: a query is quantised to t = (hi << lo_bits) + lo with hi in [-127, 127], lo in [-2^(lo_bits-1), 2^(lo_bits-1));
+  // the filter value of a row is (H << lo_bits) + L, H / L its integer dot products with the two planes (prep_q8_kernel)
+  uint32_t lo_bits;
 };
 
 // tiles [lo, hi) of row stream `stream` out of S streams over T tiles.  Streams s with equal s & 7 share an XCD label when the
@@ -901,7 +904,7 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
                                                       float max_row_norm, signed char* __restrict__ qhi,
                                                       signed char* __restrict__ qlo, float* __restrict__ qscale,
                                                       float* __restrict__ qinv, float* __restrict__ ebound,
-                                                      float* __restrict__ slack, float* __restrict__ qdelta, uint32_t* __restrict__ overflow) {
+                                                      float* __restrict__ slack, float* __restrict__ qdelta, uint32_t* __restrict__ overflow, uint32_t lo_bits) {
   __shared__ float red_max[4], red_ss[4];
   __shared__ uint32_t red_lo[4];
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
@@ -919,14 +922,15 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
   __syncthreads();
   mx = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
   ss = (red_ss[0] + red_ss[1]) + (red_ss[2] + red_ss[3]);
-  const float sq = (mx > 0.f && mx < 3.0e38f) ? mx / 16256.f : 1.f;
+  const int tmax = 127 << lo_bits, half = 1 << (lo_bits - 1);   // lo_bits = 7: 15-bit queries, |t| <= 16256
+  const float sq = (mx > 0.f && mx < 3.0e38f) ? mx / static_cast<float>(tmax) : 1.f;
   const float isq = 1.0f / sq;
   uint32_t lo2 = 0;                               // sum of lo^2 (exact: <= dim * 4096)
   for (uint32_t i = tid; i < dim; i += 256) {
     int t = static_cast<int>(rintf(src[i] * isq));
-    t = t > 16256 ? 16256 : (t < -16256 ? -16256 : t);
-    const int hi = (t + 64) >> 7;                 // floor((t+64)/128), arithmetic shift
-    const int lo = t - (hi << 7);                 // in [-64, 63]
+    t = t > tmax ? tmax : (t < -tmax ? -tmax : t);
+    const int hi = (t + half) >> lo_bits;         // floor((t + half) / 2^lo_bits), arithmetic shift
+    const int lo = t - (hi << lo_bits);           // in [-half, half)
     qhi[static_cast<uint64_t>(q) * sdim + i] = static_cast<signed char>(hi);
     qlo[static_cast<uint64_t>(q) * sdim + i] = static_cast<signed char>(lo);
     lo2 += static_cast<uint32_t>(lo * lo);
@@ -1087,7 +1091,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * j + i;
-        fv[r] = static_cast<float>(acc_hi[r] * 128 + acc_lo[r]) * scv[i];
+        fv[r] = static_cast<float>((acc_hi[r] << sa.lo_bits) + acc_lo[r]) * scv[i];
       }
     }
     float fmx = vmax3(fv[0], fv[1], fv[2]);
@@ -1218,6 +1222,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   for (int f = 0; f < NB * KSTEPS; ++f) asm volatile("" ::"a"(bq[f]));
   uint32_t qid[NB];
   float thr_s[NB], t1q[NB], inv_s[NB];
+  const float lo_unit = __builtin_bit_cast(float, (127u - sa.lo_bits) << 23);   // 2^-lo_bits: the first stage compares H alone
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     qid[nb] = qbase + nb * 32 + r31;
@@ -1227,7 +1232,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     // first-stage threshold for H * scale (the factor 128 moved to this side, exactly): a little below
     // T - delta, the margin covering the fp32 roundings of both stages' values
     const float T = thr_s[nb];
-    t1q[nb] = real ? (T - (1.001f * qdelta[qid[nb]] + 2e-6f * fabsf(T) + 1e-5f)) * 0.0078125f : __builtin_huge_valf();
+    t1q[nb] = real ? (T - (1.001f * qdelta[qid[nb]] + 2e-6f * fabsf(T) + 1e-5f)) * lo_unit : __builtin_huge_valf();
     asm volatile("" ::"v"(thr_s[nb]), "v"(inv_s[nb]), "v"(t1q[nb]));
   }
   const bool wave_has_queries = qbase < nq;
@@ -1291,7 +1296,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
       part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.w), static_cast<int>(lo.w), part, false);
     }
     part = wave_sum_i32(part);                                             // exact: integer sum
-    const float fv = static_cast<float>(pend_H * 128 + part) * pend_scale;
+    const float fv = static_cast<float>((pend_H << sa.lo_bits) + part) * pend_scale;
     if (fv >= pend_thr) {
       if (lane == 0 && wcnt < FILTER_LOGCAP) mylog[wcnt] = Hit{fv * pend_inv, pend_row, pend_qid, 0u};
       ++wcnt;
@@ -1439,7 +1444,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(lo));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float fv = static_cast<float>(acc[mb][nb][r] * 128 + lo[r]) * scv[mb][r];
+          const float fv = static_cast<float>((acc[mb][nb][r] << sa.lo_bits) + lo[r]) * scv[mb][r];
           const bool hit = fv >= thr_s[nb];
           const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
           if (m) {
@@ -1482,33 +1487,39 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
 // MFMAs of the block.  Same survivors, same filter scores (test_int8_two_stage_kernel_matches_two_plane_kernel).
 // ------------------------------------------------------------------------------------------------
 // VAR (diagnostic builds, STAMP only; wrong results): 1 = no test and no rare path (the pipelined structure alone), 2 = test but no rare path,
-// 3 = rare path without consuming the deferred values, 4 = rare path entered and left at once
-template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6, int VAR = 0>
-__global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
+// 3 = rare path without consuming the deferred values, 4 = rare path entered and left at once; 5 = the production loop (right results) reporting
+// the cycles wave 0 spent inside rare_path (high word) and consume_slots (low word) instead of the loop's cycle count
+// WPB = 8: the same 256 queries per workgroup on 8 waves of 32 (NB = 1), two waves per SIMD with 256 registers each: a wave's
+// LDS-DMA issue, ring priming, barrier waits and rare path run beside its SIMD partner's MFMAs.
+template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6, int VAR = 0, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
     const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
     const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qinv,
     const float* __restrict__ qdelta, Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t* __restrict__ prog,
     uint32_t sync_mask, uint32_t sync_lead, uint32_t* __restrict__ stage_counts) {
-  constexpr int NB = 2, MB = 2;
+  static_assert(WPB == 4 || WPB == 8, "4 waves x 64 queries or 8 waves x 32 queries");
+  constexpr int NB = 8 / WPB, MB = 2;
+  constexpr int NV = 16 * NB;                                // values a lane tests per row block
   constexpr int KSTEPS = DIM / 32;
   constexpr int ROW_BYTES = DIM;
   constexpr int TROWS = FILTER_ROWS * MB;
   constexpr int NSTAGE = 3;
   constexpr int DATA_BYTES = TROWS * ROW_BYTES;
-  constexpr int STAGE_BYTES = DATA_BYTES + 4 * 256;          // the tile + one 256-byte copy of its 64 row scales per wave
-  constexpr int NSLOT_DEFER = 4, SCRATCH_BYTES = NSLOT_DEFER * DIM;   // per wave: lo-plane rows of up to 4 deferred values
+  constexpr int SC_COPIES = WPB == 4 ? 4 : 1;                // 8 waves: every wave loads the same 256 bytes to the same place (the LDS is full)
+  constexpr int STAGE_BYTES = DATA_BYTES + SC_COPIES * 256;  // the tile + 256-byte copies of its 64 row scales
+  constexpr int NSLOT_DEFER = 16 / WPB, SCRATCH_BYTES = NSLOT_DEFER * DIM;   // per wave: lo-plane rows of up to 4 (2) deferred values
   constexpr int PIECES = DATA_BYTES / 1024;
-  constexpr int PPW = PIECES / 4;
+  constexpr int PPW = PIECES / WPB;
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
   static_assert(DIM % 256 == 0 && DIM <= 768, "row stride multiple of 256 bytes; int32 range of 128*H + L");
-  static_assert(PIECES % 4 == 0 && KSTEPS % PPW == 0 && KSTEPS % 2 == 0 && KSTEPS >= 8, "shape");
-  static_assert(NSTAGE * STAGE_BYTES + 4 * SCRATCH_BYTES <= 160 * 1024 && PPW + 1 < 64 && DIM % 16 == 0 && DIM / 16 <= 64, "LDS / vmcnt range");
+  static_assert(PIECES % WPB == 0 && KSTEPS % PPW == 0 && KSTEPS % 2 == 0 && KSTEPS >= 8, "shape");
+  static_assert(NSTAGE * STAGE_BYTES + WPB * SCRATCH_BYTES <= 160 * 1024 && PPW + 1 < 64 && DIM % 16 == 0 && DIM / 16 <= 64, "LDS / vmcnt range");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r31 = lane & 31, hsel = lane >> 5;
-  const uint32_t wave_gid = blockIdx.x * 4 + wave;
+  const uint32_t wave_gid = blockIdx.x * WPB + wave;
 
   const uint32_t nwg = gridDim.x, b = blockIdx.x;
   const uint32_t S = nwg / QT;
@@ -1523,7 +1534,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   if (NT == 0) return;
 
   // stationary operand: hi plane of this wave's 2 blocks of 32 queries, all of K, in AGPRs
-  const uint32_t qbase = qt * (128u * NB) + wave * (32u * NB);
+  const uint32_t qbase = qt * 256u + wave * (32u * NB);
   float4_t bq[NB * KSTEPS];
 #pragma unroll
   for (int f = 0; f < NB * KSTEPS; ++f) {
@@ -1534,6 +1545,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   for (int f = 0; f < NB * KSTEPS; ++f) asm volatile("" ::"a"(bq[f]));
   uint32_t qid[NB];
   float thr_s[NB], t1q[NB], inv_s[NB];
+  const float lo_unit = __builtin_bit_cast(float, (127u - sa.lo_bits) << 23);   // 2^-lo_bits: the first stage compares H alone
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     qid[nb] = qbase + nb * 32 + r31;
@@ -1541,7 +1553,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     thr_s[nb] = real ? thr[qid[nb]] * qscale[qid[nb]] : __builtin_huge_valf();
     inv_s[nb] = real ? qinv[qid[nb]] : 0.f;
     const float T = thr_s[nb];
-    t1q[nb] = real ? (T - (1.001f * qdelta[qid[nb]] + 2e-6f * fabsf(T) + 1e-5f)) * 0.0078125f : __builtin_huge_valf();   // as filter_i8w_kernel
+    t1q[nb] = real ? (T - (1.001f * qdelta[qid[nb]] + 2e-6f * fabsf(T) + 1e-5f)) * lo_unit : __builtin_huge_valf();   // as filter_i8w_kernel
     asm volatile("" ::"v"(thr_s[nb]), "v"(inv_s[nb]), "v"(t1q[nb]));
   }
   const bool wave_has_queries = qbase < nq;
@@ -1564,7 +1576,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     glds16(src_off[i], gbase + static_cast<uint64_t>(row0) * ROW_BYTES, lds_base + buf * STAGE_BYTES + (wave * PPW + i) * 1024);
   };
   auto issue_scales = [&](uint32_t row0, uint32_t buf) {
-    if (lane < 8 * MB) glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 256);
+    if (lane < 8 * MB) glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + (wave % SC_COPIES) * 256);
   };
 #pragma unroll
   for (int st = 0; st < NSTAGE - 1; ++st) {
@@ -1615,7 +1627,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
         part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x[i].w), static_cast<int>(lo.w), part, false);
       }
       part = wave_sum_i32(part);                                           // exact: integer sum
-      const float fv = static_cast<float>(pend_H[i] * 128 + part) * pend_scale[i];
+      const float fv = static_cast<float>((pend_H[i] << sa.lo_bits) + part) * pend_scale[i];
       if (fv >= pend_thr[i]) {                     // (a slot given up by the block path carries thr = +inf)
         if (lane == 0 && wcnt < FILTER_LOGCAP) mylog[wcnt] = Hit{fv * pend_inv[i], pend_row[i], pend_qid[i], 0u};
         ++wcnt;
@@ -1634,7 +1646,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256 + mb * FILTER_ROWS * ROW_BYTES);
   };
   auto load_scales = [&](const char* stage, int mb) {
-    const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 256);
+    const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + (wave % SC_COPIES) * 256);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(sc_lds + 32 * mb + 8 * j + 4 * hsel);
@@ -1644,15 +1656,15 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   // Stage-1 test of a block (32 values: query block v / 16, accumulator register v % 16), software-pipelined over the MFMA
   // slots so that the (at most 3) VALU instructions behind one MFMA never depend on each other: slot j converts the values
   // of step j, multiplies those of step j - 1 by their row scales and folds those of step j - 2 into the running maxima.
-  float tc[32], tm[32];
+  float tc[NV], tm[NV];
   auto test_step = [&](const intx16 (&a)[NB], int j, int vps) {
     if constexpr (VAR == 1) return;
 #pragma unroll
-    for (int v = j * vps; v < (j + 1) * vps; ++v) if (v >= 0 && v < 32) tc[v] = static_cast<float>(a[v / 16][v % 16]);
+    for (int v = j * vps; v < (j + 1) * vps; ++v) if (v >= 0 && v < NV) tc[v] = static_cast<float>(a[v / 16][v % 16]);
 #pragma unroll
-    for (int v = (j - 1) * vps; v < j * vps; ++v) if (v >= 0 && v < 32) tm[v] = tc[v] * scv[v % 16];
+    for (int v = (j - 1) * vps; v < j * vps; ++v) if (v >= 0 && v < NV) tm[v] = tc[v] * scv[v % 16];
 #pragma unroll
-    for (int v = (j - 2) * vps; v < (j - 1) * vps; ++v) if (v >= 0 && v < 32 && (v & 1)) mx[v / 16][(v % 16) / 4] = vmax3(mx[v / 16][(v % 16) / 4], tm[v - 1], tm[v]);
+    for (int v = (j - 2) * vps; v < (j - 1) * vps; ++v) if (v >= 0 && v < NV && (v & 1)) mx[v / 16][(v % 16) / 4] = vmax3(mx[v / 16][(v % 16) / 4], tm[v - 1], tm[v]);
   };
   auto reset_max = [&]() {
 #pragma unroll
@@ -1663,9 +1675,10 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
   float flagv = -1.f;                              // >= 0 iff some value of the tested block reaches its first-stage threshold
   auto combine_flags = [&]() {                     // behind the half's last MFMA
     if constexpr (VAR == 1) return;
-    const float m0 = vmax3(vmax3(mx[0][0], mx[0][1], mx[0][2]), mx[0][3], mx[0][3]) - t1q[0];
-    const float m1 = vmax3(vmax3(mx[1][0], mx[1][1], mx[1][2]), mx[1][3], mx[1][3]) - t1q[1];
-    flagv = vmax3(m0, m1, m1);
+    float m[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) m[nb] = vmax3(vmax3(mx[nb][0], mx[nb][1], mx[nb][2]), mx[nb][3], mx[nb][3]) - t1q[nb];
+    flagv = NB == 2 ? vmax3(m[0], m[NB - 1], m[NB - 1]) : m[0];
   };
   auto any_flag = [&]() -> bool { return __builtin_amdgcn_ballot_w64(flagv >= 0.f) != 0; };
   // rare path of one tested block: `a` its accumulators, `stage` / `row0` its tile, mb its row block.  Returns the number of
@@ -1729,9 +1742,9 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
       ++n_stage2;
       const signed char* ql = qlo + static_cast<uint64_t>(qbase + nb * 32 + r31) * DIM + 16 * hsel;
       intx16 lo;
-      constexpr int HALF = KSTEPS / 2;
+      constexpr int NCH = WPB == 8 ? 4 : 2, HALF = KSTEPS / NCH;      // query lo-plane fragments held at a time (8 waves: 256 registers per wave)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NCH; ++h) {
         float4_t bl[HALF];
 #pragma unroll
         for (int s = 0; s < HALF; ++s) bl[s] = *reinterpret_cast<const float4_t*>(ql + 32 * (h * HALF + s));
@@ -1744,7 +1757,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
       asm volatile("s_nop 15\n\ts_nop 15" : "+v"(lo));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float fv = static_cast<float>(a[nb][r] * 128 + lo[r]) * scv[r];
+        const float fv = static_cast<float>((a[nb][r] << sa.lo_bits) + lo[r]) * scv[r];
         const bool hit = fv >= thr_s[nb];
         const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
         if (m) {
@@ -1759,6 +1772,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
 
   uint32_t sync_strikes = 0;
   uint64_t stamp_c = 0, stamp_r = 0;
+  [[maybe_unused]] uint64_t rare_acc = 0, cons_acc = 0;     // VAR 5: cycles this wave spent inside rare_path / consume_slots
   if constexpr (STAMP) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   const uint32_t xw_t0 = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
   for (uint32_t t = 0; t < NT; ++t) {
@@ -1780,8 +1794,8 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     // Behind every MFMA at most one value of the other block's test (slots W0 .. W0 + 31 of the half's 2 KSTEPS MFMAs:
     // <= 3 VALU instructions inside the MFMA's 24 free issue cycles).  The A-fragment ring is primed per half: keeping it
     // alive across the rare path between the halves costs more registers than the file has.
-    constexpr int NSLOT = 2 * KSTEPS, W0 = NSLOT / 4 < 8 ? NSLOT / 4 : 8, VPS = (32 + NSLOT - W0 - 4) / (NSLOT - W0 - 3);   // values per slot: 1 at d = 768
-    static_assert(VPS >= 1 && W0 + (32 + VPS - 1) / VPS + 1 <= NSLOT - 2 && (VPS == 1 || VPS % 2 == 0), "the three test stages end before the half's last MFMA");
+    constexpr int NSLOT = NB * KSTEPS, W0 = NB == 1 ? (NSLOT / 6 < 4 ? NSLOT / 6 : 4) : (NSLOT / 4 < 8 ? NSLOT / 4 : 8), VPS = (NV + NSLOT - W0 - 4) / (NSLOT - W0 - 3);   // values per slot: 1 at d = 768
+    static_assert(VPS >= 1 && W0 + (NV + VPS - 1) / VPS + 1 <= NSLOT - 2 && (VPS == 1 || VPS % 2 == 0), "the three test stages end before the half's last MFMA");
     // ---- first half: block 0 of tile t  ||  test of block 1 of tile t-1 (t == 0: garbage, tested and ignored) ----------
     load_scales(prev_stage, 1);
     reset_max();
@@ -1795,14 +1809,18 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
       for (int nb = 0; nb < NB; ++nb) {
         if (s == 0) NVDB_MFMA_I8_ZERO(acc0[nb], av, bq[nb * KSTEPS]);
         else NVDB_MFMA_I8_ACC(acc0[nb], av, bq[nb * KSTEPS + s]);
-        const int w = 2 * s + nb;
+        const int w = NB * s + nb;
         test_step(acc1, w - W0, VPS);
         if (w == NSLOT - 1) combine_flags();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     young_loads = 0;
-    if ((VAR == 0 || VAR >= 3) && t > 0 && any_flag()) young_loads = rare_path(acc1, prev_stage, tile_row0(t - 1), 1);
+    if ((VAR == 0 || VAR >= 3) && t > 0 && any_flag()) {
+      const uint64_t r0 = VAR == 5 ? __builtin_amdgcn_s_memtime() : 0;
+      young_loads = rare_path(acc1, prev_stage, tile_row0(t - 1), 1);
+      if constexpr (VAR == 5) rare_acc += __builtin_amdgcn_s_memtime() - r0;
+    }
     if constexpr (VAR == 1 || VAR == 2) { asm volatile("" ::"v"(flagv)); }   // keep this half's test alive
     __builtin_amdgcn_s_barrier();                                          // B: nobody reads the stage of tile t-1 any more
     // ---- second half: block 1 of tile t  ||  loads of tile t+2, test of block 0 of tile t ---------------------------
@@ -1818,7 +1836,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
       for (int nb = 0; nb < NB; ++nb) {
         if (s == 0) NVDB_MFMA_I8_ZERO(acc1[nb], av, bq[nb * KSTEPS]);
         else NVDB_MFMA_I8_ACC(acc1[nb], av, bq[nb * KSTEPS + s]);
-        const int w = 2 * s + nb;
+        const int w = NB * s + nb;
         test_step(acc0, w - W0, VPS);
         if (w == NSLOT - 1) combine_flags();
         __builtin_amdgcn_sched_barrier(0);
@@ -1828,8 +1846,16 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
       __builtin_amdgcn_sched_barrier(0);
     }
     // what was deferred during the PREVIOUS tile is at least one tile old now; behind it: this tile's deferred loads and its PPW + 1 pieces
-    if (pend_old) consume_slots(pend_old, PPW + 1 + young_loads);
-    if ((VAR == 0 || VAR >= 3) && any_flag()) rare_path(acc0, stage, tile_row0(t), 0);
+    {
+      const uint64_t r0 = VAR == 5 ? __builtin_amdgcn_s_memtime() : 0;
+      if (pend_old) consume_slots(pend_old, PPW + 1 + young_loads);
+      if constexpr (VAR == 5) { const uint64_t r1 = __builtin_amdgcn_s_memtime(); cons_acc += r1 - r0; }
+    }
+    if ((VAR == 0 || VAR >= 3) && any_flag()) {
+      const uint64_t r0 = VAR == 5 ? __builtin_amdgcn_s_memtime() : 0;
+      rare_path(acc0, stage, tile_row0(t), 0);
+      if constexpr (VAR == 5) rare_acc += __builtin_amdgcn_s_memtime() - r0;
+    }
     pend_old = pend_mask;                                                  // everything deferred during this tile: due at the end of the next
     if constexpr (VAR == 1 || VAR == 2) { asm volatile("" ::"v"(flagv)); }
   }
@@ -1839,14 +1865,16 @@ __global__ __launch_bounds__(256, 1) void filter_i8p_kernel(
     load_scales(last_stage, 1);
     reset_max();
 #pragma unroll
-    for (int j = 0; j < 34; ++j) test_step(acc1, j, 1);
+    for (int j = 0; j < NV + 2; ++j) test_step(acc1, j, 1);
     combine_flags();
     if (pend_mask) consume_slots(pend_mask, 0);
     if ((VAR == 0 || VAR >= 3) && any_flag()) rare_path(acc1, last_stage, tile_row0(NT - 1), 1);
     if (pend_mask) consume_slots(pend_mask, 0);
   }
   if constexpr (STAMP) {
-    const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c, dr = __builtin_amdgcn_s_memrealtime() - stamp_r;
+    uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c;
+    const uint64_t dr = __builtin_amdgcn_s_memrealtime() - stamp_r;
+    if constexpr (VAR == 5) dc = (rare_acc << 32) | (cons_acc & 0xFFFFFFFFull);   // this build reports those instead of the loop's cycles
     if (wave == 0 && lane == 0) {
       uint64_t* out = reinterpret_cast<uint64_t*>(prog + static_cast<uint64_t>(gridDim.x) * 8) + static_cast<uint64_t>(blockIdx.x) * 2;
       out[0] = dc; out[1] = dr;

@@ -69,6 +69,7 @@ struct nvdb_hip_ctx {
   uint32_t fdim = 0;                               // dim the filter kernels run at (>= dim; == dim without padding)
   DevBuf qdelta;                                   // int8: per query, what the lo plane can add to a filter value
   int64_t opt_i8_wide = 1;
+  int64_t opt_i8_waves8 = 0;                       // ... on 8 waves of 32 queries (two per SIMD) instead of 4 of 64: 1 % slower (profiles/r02_i8_waves8_ab.txt), off
   int64_t opt_i8_pipe = 1;                         // int8 batches > 128: software-pipelined build (stage-1 test in the shadow of the other row block's MFMAs)
   int64_t opt_waves8 = 1;                          // d=768: 8-wave workgroups (two waves per SIMD, 32 queries each) for the fp16 m16 kernel: +2.3 % (0: four waves x 64 queries)
   void* pinned = nullptr;                           // pinned host staging of small calls: status words, results, queries
@@ -87,6 +88,9 @@ struct nvdb_hip_ctx {
   DevBuf rq, rcand, rout_ids, rout_dist;           // refine
   DevBuf xcdw;                                     // XCD balance: 8 speed weights + 16 accumulators (kernels_filter.h ScatterArgs::xcdw)
   int64_t opt_xcd_balance = 1;
+  int64_t opt_i8_lo_bits = 7;                      // int8: bits of a quantised query's lo plane (ScatterArgs::lo_bits)
+  int64_t opt_boot_tiles = 0;                      // threshold bootstrap over this many 32-row tile maxima (0: max(64, 8k))
+  int64_t dbg_rows = 0;                            // developer build: rows the stamped launches of nvdb_hip_debug_clock_i8 cover (0: the corpus)
   DevBuf lk_scores, lk_sel, lk_hist, lk_state;     // any-k path (kernels_largek.h): score matrix of a query sub-batch, selected keys, radix state
   int64_t opt_refine_pinned = 0;                   // refine host call: stage queries / candidates / results through pinned host buffers (reference CUDA_PINNED)
   void* rpinned = nullptr;                         // ... [queries | candidates | out ids | out dist]
@@ -352,7 +356,7 @@ nvdb_status next_prog_region(nvdb_hip_ctx* c, hipStream_t s, uint32_t nwg, uint3
 ScatterArgs scatter_args(nvdb_hip_ctx* c, uint32_t cap, uint32_t trows = 0) {
   ScatterArgs a{static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), static_cast<uint32_t*>(c->overflow.p),
                 static_cast<uint32_t*>(c->misc.p) + 1, cap, static_cast<uint32_t>(c->n), 1u, 0u, 0u,
-                c->opt_xcd_balance ? static_cast<float*>(c->xcdw.p) : nullptr};
+                c->opt_xcd_balance ? static_cast<float*>(c->xcdw.p) : nullptr, static_cast<uint32_t>(c->opt_i8_lo_bits)};
   if (trows && c->perm_on) {
     const bool padded = c->owned || c->shadow16 != nullptr || c->shadow8 != nullptr;
     const uint32_t n = static_cast<uint32_t>(c->n);
@@ -583,7 +587,7 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   if (nwg == 0) nwg = QT;
   nvdb_status st;
   if ((row_hi - row_lo) % I8W_TILE_ROWS) return fail(c, NVDB_ERR_INTERNAL, "int8 two-stage kernel: row range is not a multiple of its 64-row tile");
-  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 8 * FILTER_LOGCAP * sizeof(Hit)))) return st;
   const signed char* qhi = static_cast<const signed char*>(c->q16.p);
   const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * DIM;
   uint32_t* counts = static_cast<uint32_t*>(c->misc.p) + 4;            // [4], [5]: tiles past stage 0 / stage 1
@@ -599,26 +603,30 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
   }
-#define NVDB_I8P_LAUNCH(SYNCV, PROG, MASK, LEAD)                                                                                  \
+#define NVDB_I8P_LAUNCH(SYNCV, PROG, MASK, LEAD, WPBV)                                                                            \
   {                                                                                                                             \
-    constexpr size_t ldsp = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + 4 * 256) + 16 * DIM;   /* stages + 4 waves x 4 deferred lo-plane rows */ \
-    const void* fn = reinterpret_cast<const void*>(filter_i8p_kernel<DIM, SYNCV>);                                              \
+    /* stages (tile + scale copies) + per wave the deferred lo-plane rows: 4 waves x 4, 8 waves x 2 */                           \
+    constexpr size_t ldsp = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + (WPBV == 4 ? 4 : 1) * 256) + 16 * DIM;              \
+    const void* fn = reinterpret_cast<const void*>(filter_i8p_kernel<DIM, SYNCV, false, 6, 0, WPBV>);                           \
     if (!c->lds_attr_set.count(fn)) {                                                                                           \
       HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsp)));                   \
       c->lds_attr_set.insert(fn);                                                                                               \
     }                                                                                                                           \
-    hipExtLaunchKernelGGL((filter_i8p_kernel<DIM, SYNCV>), dim3(nwg), dim3(256), ldsp, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
+    hipExtLaunchKernelGGL((filter_i8p_kernel<DIM, SYNCV, false, 6, 0, WPBV>), dim3(nwg), dim3(64 * WPBV), ldsp, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
   }
   const bool pipe = (NB == 2) && c->opt_i8_pipe;
+  const bool w8 = pipe && c->opt_i8_waves8;
   if (sync) {
     uint32_t* prog = nullptr;
     if ((st = next_prog_region(c, s, nwg, &prog))) return st;
-    if (pipe) NVDB_I8P_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead))
+    if (w8) NVDB_I8P_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), 8)
+    else if (pipe) NVDB_I8P_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), 4)
     else NVDB_I8W_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead))
   } else {
-    if (pipe) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u)
+    if (w8) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 8)
+    else if (pipe) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 4)
     else NVDB_I8W_LAUNCH(false, nullptr, 0u, 0u)
   }
 #undef NVDB_I8W_LAUNCH
@@ -850,7 +858,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
                                           static_cast<signed char*>(c->q16.p) + static_cast<size_t>(nq_pad) * c->fdim,
                                           static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
                                           static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p), static_cast<float*>(c->qdelta.p),
-                                          static_cast<uint32_t*>(c->overflow.p));
+                                          static_cast<uint32_t*>(c->overflow.p), static_cast<uint32_t>(c->opt_i8_lo_bits));
   else
     // fp32 corpus: the shadow adds 2^-11 relative (normal halves) and <= 2^-25 absolute per element (subnormal halves)
     prep_q16_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->fdim, c->max_norm, c->dtype == NVDB_DTYPE_F32 ? FILTER_REL_F16 + 4.9e-4f : FILTER_REL_F16,
@@ -877,7 +885,9 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   if (k_wide) growth = std::max<uint64_t>(2, std::min<uint64_t>(growth, cap / (3ull * k_eff)));     // k * (growth - 1) + k + band <= cap
   // T tile maxima with T >= 8k: their k-th largest is then close to the k-th best of the 32*T rows (with T == k it
   // would be the smallest tile maximum, a uselessly weak threshold)
-  const uint32_t boot_rows = FILTER_ROWS * std::max<uint32_t>(64u, 8u * k_eff);
+  uint32_t boot_tiles = std::max<uint32_t>(64u, 8u * k_eff);
+  if (c->opt_boot_tiles > 0) boot_tiles = std::max<uint32_t>(boot_tiles, std::min<uint32_t>(static_cast<uint32_t>(c->opt_boot_tiles), cap));
+  const uint32_t boot_rows = FILTER_ROWS * boot_tiles;
   const bool mfma_boot = c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
                          boot_rows / FILTER_ROWS <= cap &&
                          (c->dtype == NVDB_DTYPE_I8 || c->fdim <= 768);    // no bootstrap build of the 16-row-tile kernel: exact bootstrap chunk
@@ -1110,7 +1120,13 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "f32_shadow") { c->opt_f32_shadow = value ? 1 : 0; }
   else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }
   else if (k == "i8_pipe") { c->opt_i8_pipe = value ? 1 : 0; }
+  else if (k == "i8_waves8") { c->opt_i8_waves8 = value ? 1 : 0; }
   else if (k == "xcd_balance") { c->opt_xcd_balance = value ? 1 : 0; }
+  else if (k == "i8_lo_bits") { if (value < 2 || value > 7) return fail(c, NVDB_ERR_INVALID, "i8_lo_bits must be in [2,7]"); c->opt_i8_lo_bits = value; }
+  else if (k == "boot_tiles") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "boot_tiles out of range"); c->opt_boot_tiles = value; }
+#ifdef NVDB_HIP_DEV
+  else if (k == "debug_rows") { c->dbg_rows = value < 0 ? 0 : value; }
+#endif
   else if (k == "waves8") { c->opt_waves8 = value ? 1 : 0; }
   else if (k == "tile_permute") { c->opt_tile_permute = value ? 1 : 0; }
   else if (k == "rescore8") { c->opt_rescore8 = value < 0 ? 0 : (value > 2 ? 2 : value); }
@@ -1532,7 +1548,8 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
   if ((st = ensure(c, c->prog, std::max(prog_bytes + stamp_bytes, static_cast<size_t>(PROG_SLOTS) * c->num_cu * 8 * 4)))) return st;
   if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
   constexpr size_t lds = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + 4 * 1024) + 4096;
-  const uint32_t n_al = static_cast<uint32_t>(c->n / I8W_TILE_ROWS * I8W_TILE_ROWS);
+  const uint64_t n_dbg = c->dbg_rows > 0 ? std::min<uint64_t>(c->n, static_cast<uint64_t>(c->dbg_rows)) : c->n;
+  const uint32_t n_al = static_cast<uint32_t>(n_dbg / I8W_TILE_ROWS * I8W_TILE_ROWS);
   const signed char* qhi = static_cast<const signed char*>(c->q16.p);
   const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * 768;
   hipEvent_t e0, e1;
@@ -1579,6 +1596,7 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
       case 12: NVDB_CLK_I8P(2) break;             // ... test in the MFMA shadow, rare path never taken
       case 13: NVDB_CLK_I8P(3) break;             // ... rare path, deferred values never consumed
       case 14: NVDB_CLK_I8P(4) break;             // ... rare path entered and left at once
+      case 15: NVDB_CLK_I8P(5) break;             // ... production loop, cycles inside rare_path / consume_slots (wave 0 of every workgroup)
       default: return fail(c, NVDB_ERR_INVALID, "debug: unknown variant");
     }
     HIPCHK(c, hipGetLastError());
@@ -1596,9 +1614,14 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
   std::vector<uint64_t> stamps(static_cast<size_t>(nwg) * 2);
   HIPCHK(c, hipMemcpy(stamps.data(), static_cast<const char*>(c->prog.p) + prog_bytes, stamp_bytes, hipMemcpyDeviceToHost));
   std::vector<float> ghz;
-  for (uint32_t w = 0; w < nwg; ++w)
-    if (stamps[2 * w + 1]) ghz.push_back(static_cast<float>(static_cast<double>(stamps[2 * w]) / static_cast<double>(stamps[2 * w + 1]) * 0.1));
-  std::sort(ghz.begin(), ghz.end());
+  double rare_cyc = 0.0, cons_cyc = 0.0;
+  for (uint32_t w = 0; w < nwg; ++w) {
+    if (!stamps[2 * w + 1]) continue;
+    if (variant == 15) { rare_cyc += static_cast<double>(stamps[2 * w] >> 32); cons_cyc += static_cast<double>(stamps[2 * w] & 0xFFFFFFFFull); }
+    else ghz.push_back(static_cast<float>(static_cast<double>(stamps[2 * w]) / static_cast<double>(stamps[2 * w + 1]) * 0.1));
+  }
+  if (variant == 15) { ghz.assign(3, static_cast<float>(rare_cyc / nwg)); ghz[2] = static_cast<float>(cons_cyc / nwg); }   // out[2] / out[3]: mean cycles of a workgroup's wave 0 inside rare_path / consume_slots
+  else std::sort(ghz.begin(), ghz.end());
   out4[0] = ms;
   out4[1] = ghz.empty() ? 0.f : ghz[ghz.size() / 2];
   out4[2] = ghz.empty() ? 0.f : ghz.front();
@@ -1607,6 +1630,12 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
   HIPCHK(c, hipMemcpy(counts, static_cast<uint32_t*>(c->misc.p) + 4, 8, hipMemcpyDeviceToHost));
   out4[4] = static_cast<float>(counts[0]) / burst;
   out4[5] = static_cast<float>(counts[1]) / burst;
+  double sum_us = 0.0, max_us = 0.0;                // the tile loop alone, per workgroup (100 MHz ticks)
+  uint32_t nstamped = 0;
+  for (uint32_t w = 0; w < nwg; ++w)
+    if (stamps[2 * w + 1]) { const double us = static_cast<double>(stamps[2 * w + 1]) * 0.01; sum_us += us; max_us = std::max(max_us, us); ++nstamped; }
+  out4[6] = nstamped ? static_cast<float>(sum_us / nstamped) : 0.f;
+  out4[7] = static_cast<float>(max_us);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return NVDB_OK;
 }

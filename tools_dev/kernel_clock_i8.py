@@ -18,8 +18,8 @@ ctx.set_option("path", 2); ctx.search_batch(q, 10)
 st = ctx.stats()
 print(f"search: {st}", flush=True)
 names = {10: "software-pipelined build (filter_i8p_kernel, the default)", 11: "pipelined structure alone (no test, no rare path)", 12: "pipelined, test in the MFMA shadow, rare path never taken", 13: "pipelined, rare path without consuming the deferred values", 14: "pipelined, rare path entered and left at once", 0: "filter_i8w_kernel loop", 1: "no stage 2 (lo plane never multiplied)", 2: "no stage-1 test either (stream + hi-plane MFMAs)", 3: "the same without the per-tile barrier"}
-for var in (10, 14, 12, 11, 0, 10, 14, 12):
-    out = (C.c_float * 6)()
+for var in (10, 12, 11):
+    out = (C.c_float * 8)()
     rc = lib.nvdb_hip_debug_clock_i8(ctx.h, var, nq, secs, out)
     assert rc == 0, lib.nvdb_hip_last_error(ctx.h)
     ms, med, lo, hi = out[0], out[1], out[2], out[3]
@@ -29,3 +29,11 @@ for var in (10, 14, 12, 11, 0, 10, 14, 12):
     print(f"[{names[var]}] whole-corpus launch {ms:.3f} ms = {tops:.0f} TOP/s algorithmic (hi plane only: half the int8 work of the two-plane kernel); "
           f"in-kernel clock median {med:.3f} GHz (min {lo:.3f}, max {hi:.3f}); MFMA pipe busy {busy:.3f}; cycles per tile {3072 / busy:.0f}; "
           f"rare-path entries {out[4]:.0f}, lo-plane MFMA blocks {out[5]:.0f} per launch ({n // 64 * 16 * 2} wave-halves)", flush=True)
+# where a rare-path entry's time goes: cycles wave 0 of every workgroup spent inside rare_path / consume_slots (variant 15)
+out = (C.c_float * 8)()
+rc = lib.nvdb_hip_debug_clock_i8(ctx.h, 15, nq, secs, out)
+assert rc == 0, lib.nvdb_hip_last_error(ctx.h)
+per_wave = out[4] / 1024.0
+print(f"[production loop, stamped inside the rare path] launch {out[0]:.3f} ms; rare-path entries {out[4]:.0f} per launch = {per_wave:.1f} per wave; "
+      f"wave 0 of a workgroup spends {out[2]:.0f} cycles inside rare_path (= {out[2] / max(per_wave, 1e-9):.0f} per entry) and {out[3]:.0f} inside consume_slots "
+      f"(= {out[3] / max(per_wave, 1e-9):.0f} per entry) of a {out[6]:.0f} us tile loop", flush=True)
