@@ -435,7 +435,7 @@ def main():
                                + (" (BASELINE configs[1])" if (N, world) == (ROWS_1GPU, 1) else " (BASELINE configs[3])" if N == ROWS_SHARDED else ""),
                    "rows_total": N, "rows_per_gpu": hi - lo, "batch": B, "k": K, "dim": D,
                    "parallelism": "1 GPU" if world == 1 else f"corpus row-sharded x{world}, RCCL all-gather of per-shard top-k",
-                   "series": "strong scaling over the 100M-row corpus; its 1-GPU point is extras.fp16_100M_batch1024 of the --gpus 1 line" if (world > 1 and N == ROWS_SHARDED) else None},
+                   "series": "strong scaling over the 100M-row corpus; its 1-GPU point is extras.fp16_100M_batch1024 (= scaling_points.fp16_100M_batch1024_qps) of the --gpus 1 line" if (world > 1 and N == ROWS_SHARDED) else None},
         "effective_hbm_GBps": (N * bpr / 1e9) / (ms_per_step * 1e-3),          # corpus bytes / pass time, all GPUs
         "parity": parity, "merge_check": merge_check,
         "self_check": "every timed step checked (sticky flags): no list overflow, no bound violation",
@@ -613,6 +613,14 @@ def main():
         except Exception as e:
             out["cpu_baseline"]["config0_fp32_500K_st"] = {"error": repr(e)}
     if rank == 0:
+        # One point of each strong-scaling series per line, so the 1/2/4/8 curves can be read off the per-N lines without
+        # mixing corpora: `value` is the 10M-row point at N = 1 and the 100M-row point at N > 1 (BASELINE configs[1] / [3]).
+        ex = out.get("extras") or {}
+        if args.dtype == "f16" and B == 1024:
+            if world == 1 and N == ROWS_1GPU:
+                out["scaling_points"] = {"fp16_10M_batch1024_qps": qps, "fp16_100M_batch1024_qps": (ex.get("fp16_100M_batch1024") or {}).get("qps")}
+            elif world > 1 and N == ROWS_SHARDED:
+                out["scaling_points"] = {"fp16_100M_batch1024_qps": qps, "fp16_10M_batch1024_qps": (ex.get("strong_10M") or {}).get("qps")}
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

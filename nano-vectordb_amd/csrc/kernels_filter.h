@@ -1469,6 +1469,59 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   scatter_own_log(mylog, wcnt, sa, lane);
 }
 
+// int8 two-stage kernel, DEFER = false: the tile loop logs every value that passes the FIRST stage (hi plane only) with its row
+// scale and H; here, after the stream, the wave finishes them: L = <row, lo plane of the query> by v_dot4 (4 lanes per entry,
+// 16 entries per step, rows re-read from L2 / HBM), fv = ((H << lo_bits) + L) * scale, and files those with fv >= T under their
+// queries -- the same survivors with the same filter scores as the in-loop second stage, without stalling the workgroup's
+// barrier for every flagged value.
+template <int DIM>
+__device__ __forceinline__ void verify_and_scatter_i8(const Hit* mylog, uint32_t wcnt, const ScatterArgs& a, int lane, const signed char* __restrict__ rows,
+                                                      const signed char* __restrict__ qlo, const float* __restrict__ thr, const float* __restrict__ qscale,
+                                                      const float* __restrict__ qinv) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own log stores (and the speculative stages) have completed
+  uint32_t n = wcnt;
+  if (n > FILTER_LOGCAP) { if (lane == 0) *a.log_overflow = 1u; n = FILTER_LOGCAP; }
+  constexpr int CPL = DIM / 64;                      // 16-byte chunks per lane (4 lanes per entry)
+  const int part4 = lane & 3;
+  for (uint32_t base = 0; base < n; base += 16) {
+    const uint32_t e = base + (static_cast<uint32_t>(lane) >> 2);
+    bool valid = e < n;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(mylog + (valid ? e : 0u));
+    // L2-served loads: the entries were written by this wave in this launch
+    const uint32_t sbits = __hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t row = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t qid = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int H = static_cast<int>(__hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    valid = valid && row < a.n_rows;
+    int part = 0;
+    if (valid) {
+      const uint4* xr = reinterpret_cast<const uint4*>(rows + static_cast<uint64_t>(row) * DIM);
+      const uint4* qr = reinterpret_cast<const uint4*>(qlo + static_cast<uint64_t>(qid) * DIM);
+      uint4 x[CPL], y[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { x[c] = xr[part4 + 4 * c]; y[c] = qr[part4 + 4 * c]; }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        part = __builtin_amdgcn_sdot4(static_cast<int>(x[c].x), static_cast<int>(y[c].x), part, false);
+        part = __builtin_amdgcn_sdot4(static_cast<int>(x[c].y), static_cast<int>(y[c].y), part, false);
+        part = __builtin_amdgcn_sdot4(static_cast<int>(x[c].z), static_cast<int>(y[c].z), part, false);
+        part = __builtin_amdgcn_sdot4(static_cast<int>(x[c].w), static_cast<int>(y[c].w), part, false);
+      }
+    }
+    part += __builtin_amdgcn_update_dpp(0, part, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    part += __builtin_amdgcn_update_dpp(0, part, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]: the entry's four lanes hold L
+    if (valid && part4 == 0) {
+      const float fv = static_cast<float>((H << a.lo_bits) + part) * __builtin_bit_cast(float, sbits);
+      if (fv >= thr[qid] * qscale[qid]) {
+        const uint32_t slot = atomicAdd(&a.cnt[qid], 1u);
+        if (slot < a.cap) a.cand[static_cast<uint64_t>(qid) * a.cap + slot] = Cand{fv * qinv[qid], row};
+        else a.overflow[qid] = 1u;
+      }
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // int8 two-stage build, software-pipelined (batches > 128: NB = 2 query blocks per wave, 64-row tiles).
 //
@@ -1491,7 +1544,9 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
 // the cycles wave 0 spent inside rare_path (high word) and consume_slots (low word) instead of the loop's cycle count
 // WPB = 8: the same 256 queries per workgroup on 8 waves of 32 (NB = 1), two waves per SIMD with 256 registers each: a wave's
 // LDS-DMA issue, ring priming, barrier waits and rare path run beside its SIMD partner's MFMAs.
-template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6, int VAR = 0, int WPB = 4>
+// DEFER = false (the default build): a value that passes the first stage is only logged in the loop and finished after the stream
+// (verify_and_scatter_i8); DEFER = true: the in-loop second stage (deferred v_dot4 slots, lo-plane MFMAs for dense blocks).
+template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6, int VAR = 0, int WPB = 4, bool DEFER = true>
 __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
     const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
@@ -1508,7 +1563,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
   constexpr int DATA_BYTES = TROWS * ROW_BYTES;
   constexpr int SC_COPIES = WPB == 4 ? 4 : 1;                // 8 waves: every wave loads the same 256 bytes to the same place (the LDS is full)
   constexpr int STAGE_BYTES = DATA_BYTES + SC_COPIES * 256;  // the tile + 256-byte copies of its 64 row scales
-  constexpr int NSLOT_DEFER = 16 / WPB, SCRATCH_BYTES = NSLOT_DEFER * DIM;   // per wave: lo-plane rows of up to 4 (2) deferred values
+  constexpr int NSLOT_DEFER = 16 / WPB, SCRATCH_BYTES = DEFER ? NSLOT_DEFER * DIM : 0;   // per wave: lo-plane rows of up to 4 (2) deferred values
   constexpr int PIECES = DATA_BYTES / 1024;
   constexpr int PPW = PIECES / WPB;
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
@@ -1770,6 +1825,32 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     return issued;
   };
 
+  // DEFER = false: log the values of a tested block that pass the first stage -- row scale, row, query, H -- for the exact
+  // finish after the stream.  Per flagged group of 4 accumulator registers one ballot per value; lanes compact into the log.
+  auto rare_log = [&](const intx16 (&a)[NB], uint32_t row0, int mb) {
+    ++n_stage1;
+    if constexpr (VAR == 4) return;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (!__builtin_amdgcn_ballot_w64(mx[nb][g] >= t1q[nb])) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          const bool hit = static_cast<float>(a[nb][r]) * scv[r] >= t1q[nb];
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+          if (m) {
+            const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+            if (hit && idx < FILTER_LOGCAP)
+              mylog[idx] = Hit{scv[r], row0 + 32u * mb + (r & 3) + 8 * (r >> 2) + 4 * hsel, qid[nb], static_cast<uint32_t>(a[nb][r])};
+            wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
+          }
+        }
+      }
+    }
+  };
+
   uint32_t sync_strikes = 0;
   uint64_t stamp_c = 0, stamp_r = 0;
   [[maybe_unused]] uint64_t rare_acc = 0, cons_acc = 0;     // VAR 5: cycles this wave spent inside rare_path / consume_slots
@@ -1818,7 +1899,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     young_loads = 0;
     if ((VAR == 0 || VAR >= 3) && t > 0 && any_flag()) {
       const uint64_t r0 = VAR == 5 ? __builtin_amdgcn_s_memtime() : 0;
-      young_loads = rare_path(acc1, prev_stage, tile_row0(t - 1), 1);
+      if constexpr (DEFER) young_loads = rare_path(acc1, prev_stage, tile_row0(t - 1), 1); else rare_log(acc1, tile_row0(t - 1), 1);
       if constexpr (VAR == 5) rare_acc += __builtin_amdgcn_s_memtime() - r0;
     }
     if constexpr (VAR == 1 || VAR == 2) { asm volatile("" ::"v"(flagv)); }   // keep this half's test alive
@@ -1853,7 +1934,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     }
     if ((VAR == 0 || VAR >= 3) && any_flag()) {
       const uint64_t r0 = VAR == 5 ? __builtin_amdgcn_s_memtime() : 0;
-      rare_path(acc0, stage, tile_row0(t), 0);
+      if constexpr (DEFER) rare_path(acc0, stage, tile_row0(t), 0); else rare_log(acc0, tile_row0(t), 0);
       if constexpr (VAR == 5) rare_acc += __builtin_amdgcn_s_memtime() - r0;
     }
     pend_old = pend_mask;                                                  // everything deferred during this tile: due at the end of the next
@@ -1868,7 +1949,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     for (int j = 0; j < NV + 2; ++j) test_step(acc1, j, 1);
     combine_flags();
     if (pend_mask) consume_slots(pend_mask, 0);
-    if ((VAR == 0 || VAR >= 3) && any_flag()) rare_path(acc1, last_stage, tile_row0(NT - 1), 1);
+    if ((VAR == 0 || VAR >= 3) && any_flag()) { if constexpr (DEFER) rare_path(acc1, last_stage, tile_row0(NT - 1), 1); else rare_log(acc1, tile_row0(NT - 1), 1); }
     if (pend_mask) consume_slots(pend_mask, 0);
   }
   if constexpr (STAMP) {
@@ -1883,7 +1964,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
   if constexpr (SYNC) { if (wave == 0 && lane == 0) __hip_atomic_store(prog + static_cast<uint64_t>(stream) * 8 + qt, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (stage_counts && lane == 0 && (n_stage1 | n_stage2)) { atomicAdd(stage_counts, n_stage1); atomicAdd(stage_counts + 1, n_stage2); }
   if (wave == 0 && lane == 0) record_xcd_speed(sa.xcdw, xcd_map, stream & 7u, NT, static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) - xw_t0);
-  scatter_own_log(mylog, wcnt, sa, lane);
+  if constexpr (DEFER) scatter_own_log(mylog, wcnt, sa, lane);
+  else verify_and_scatter_i8<DIM>(mylog, wcnt, sa, lane, rows, qlo, thr, qscale, qinv);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -70,6 +70,7 @@ struct nvdb_hip_ctx {
   DevBuf qdelta;                                   // int8: per query, what the lo plane can add to a filter value
   int64_t opt_i8_wide = 1;
   int64_t opt_i8_waves8 = 0;                       // ... on 8 waves of 32 queries (two per SIMD) instead of 4 of 64: 1 % slower (profiles/r02_i8_waves8_ab.txt), off
+  int64_t opt_i8_defer = 0;                        // pipelined build: 1 = second stage inside the tile loop (deferred v_dot4 slots), 0 = log the first stage's survivors, finish them after the stream
   int64_t opt_i8_pipe = 1;                         // int8 batches > 128: software-pipelined build (stage-1 test in the shadow of the other row block's MFMAs)
   int64_t opt_waves8 = 1;                          // d=768: 8-wave workgroups (two waves per SIMD, 32 queries each) for the fp16 m16 kernel: +2.3 % (0: four waves x 64 queries)
   void* pinned = nullptr;                           // pinned host staging of small calls: status words, results, queries
@@ -603,30 +604,34 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
   }
-#define NVDB_I8P_LAUNCH(SYNCV, PROG, MASK, LEAD, WPBV)                                                                            \
+#define NVDB_I8P_LAUNCH(SYNCV, PROG, MASK, LEAD, WPBV, DEFERV)                                                                            \
   {                                                                                                                             \
     /* stages (tile + scale copies) + per wave the deferred lo-plane rows: 4 waves x 4, 8 waves x 2 */                           \
-    constexpr size_t ldsp = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + (WPBV == 4 ? 4 : 1) * 256) + 16 * DIM;              \
-    const void* fn = reinterpret_cast<const void*>(filter_i8p_kernel<DIM, SYNCV, false, 6, 0, WPBV>);                           \
+    constexpr size_t ldsp = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + (WPBV == 4 ? 4 : 1) * 256) + (DEFERV ? 16 * DIM : 0); \
+    const void* fn = reinterpret_cast<const void*>(filter_i8p_kernel<DIM, SYNCV, false, 6, 0, WPBV, DEFERV>);                           \
     if (!c->lds_attr_set.count(fn)) {                                                                                           \
       HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsp)));                   \
       c->lds_attr_set.insert(fn);                                                                                               \
     }                                                                                                                           \
-    hipExtLaunchKernelGGL((filter_i8p_kernel<DIM, SYNCV, false, 6, 0, WPBV>), dim3(nwg), dim3(64 * WPBV), ldsp, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
+    hipExtLaunchKernelGGL((filter_i8p_kernel<DIM, SYNCV, false, 6, 0, WPBV, DEFERV>), dim3(nwg), dim3(64 * WPBV), ldsp, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
   }
   const bool pipe = (NB == 2) && c->opt_i8_pipe;
   const bool w8 = pipe && c->opt_i8_waves8;
+  const bool defer = c->opt_i8_defer != 0;
+  const uint32_t smask = static_cast<uint32_t>(c->opt_sync_every - 1), slead = static_cast<uint32_t>(c->opt_sync_lead);
   if (sync) {
     uint32_t* prog = nullptr;
     if ((st = next_prog_region(c, s, nwg, &prog))) return st;
-    if (w8) NVDB_I8P_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), 8)
-    else if (pipe) NVDB_I8P_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), 4)
-    else NVDB_I8W_LAUNCH(true, prog, static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead))
+    if (w8) NVDB_I8P_LAUNCH(true, prog, smask, slead, 8, true)              // the 8-wave variant exists with the in-loop second stage only
+    else if (pipe && defer) NVDB_I8P_LAUNCH(true, prog, smask, slead, 4, true)
+    else if (pipe) NVDB_I8P_LAUNCH(true, prog, smask, slead, 4, false)
+    else NVDB_I8W_LAUNCH(true, prog, smask, slead)
   } else {
-    if (w8) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 8)
-    else if (pipe) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 4)
+    if (w8) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 8, true)
+    else if (pipe && defer) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 4, true)
+    else if (pipe) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 4, false)
     else NVDB_I8W_LAUNCH(false, nullptr, 0u, 0u)
   }
 #undef NVDB_I8W_LAUNCH
@@ -1121,6 +1126,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }
   else if (k == "i8_pipe") { c->opt_i8_pipe = value ? 1 : 0; }
   else if (k == "i8_waves8") { c->opt_i8_waves8 = value ? 1 : 0; }
+  else if (k == "i8_defer") { c->opt_i8_defer = value ? 1 : 0; }
   else if (k == "xcd_balance") { c->opt_xcd_balance = value ? 1 : 0; }
   else if (k == "i8_lo_bits") { if (value < 2 || value > 7) return fail(c, NVDB_ERR_INVALID, "i8_lo_bits must be in [2,7]"); c->opt_i8_lo_bits = value; }
   else if (k == "boot_tiles") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "boot_tiles out of range"); c->opt_boot_tiles = value; }

@@ -76,9 +76,11 @@ def test_register_budgets_of_the_production_kernels(codegen):
             assert v["vgpr"] + v["agpr"] <= 512 and v["occ"] >= 1, (key, v)
     k = _find(by_name, "filter_i8w_kernel<768, 2, 6, true, 2, false, 0>")
     assert k["agpr"] >= 192 and k["occ"] == 1, k                      # the hi plane of 64 queries stays resident in AGPRs
-    k = _find(by_name, "filter_i8p_kernel<768, true, false, 6, 0, 4>")
-    assert k["agpr"] >= 192 and k["occ"] == 1, k                      # the pipelined build: same residency, no scratch (checked above)
-    k = _find(by_name, "filter_i8p_kernel<768, true, false, 6, 0, 8>")
+    k = _find(by_name, "filter_i8p_kernel<768, true, false, 6, 0, 4, false>")
+    assert k["agpr"] >= 192 and k["occ"] == 1 and k["sspill"] == 0, k  # the pipelined build (default: first-stage survivors logged): same residency, no scratch (checked above)
+    k = _find(by_name, "filter_i8p_kernel<768, true, false, 6, 0, 4, true>")
+    assert k["agpr"] >= 192 and k["occ"] == 1, k                      # ... with the in-loop second stage (option i8_defer)
+    k = _find(by_name, "filter_i8p_kernel<768, true, false, 6, 0, 8, true>")
     assert k["vgpr"] <= 128 and k["agpr"] <= 128 and k["agpr"] >= 96 and k["occ"] == 2, k   # its 8-wave variant (option i8_waves8): 32 queries per wave, two waves per SIMD
     k = _find(by_name, "filter_f16_kernelILi768ELi1ELi0ELi6E")
     assert k["agpr"] >= 192, k

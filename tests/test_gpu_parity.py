@@ -213,20 +213,24 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx, oracle, nq, k, d):
         queries[5] = np.round(queries[5] * 40) / 40          # few distinct levels
     ctx.set_option("path", 2)
     res, stats = {}, {}
-    # 0: two-plane kernel; 1: two-stage, software-pipelined build for batches > 128 on 8 waves of 32 queries (the default);
-    # 2: two-stage, filter_i8w_kernel; 3: the pipelined build on 4 waves of 64 queries
-    for var, (wide, pipe, w8) in enumerate(((0, 1, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0))):
+    # 0: two-plane kernel; 1: two-stage, software-pipelined build for batches > 128, first-stage survivors logged and finished
+    # after the stream (the default); 2: two-stage, filter_i8w_kernel; 3: the pipelined build with the in-loop second stage
+    # (deferred v_dot4 slots); 4: the same on 8 waves of 32 queries
+    variants = ((0, 1, 0, 0), (1, 1, 0, 0), (1, 0, 0, 0), (1, 1, 0, 1), (1, 1, 1, 1))
+    for var, (wide, pipe, w8, defer) in enumerate(variants):
         ctx.set_option("i8_wide", wide)
         ctx.set_option("i8_pipe", pipe)
         ctx.set_option("i8_waves8", w8)
+        ctx.set_option("i8_defer", defer)
         res[var] = ctx.search_batch(queries, k)
         stats[var] = ctx.stats()
         assert stats[var]["path"] == 2 and stats[var]["bound_violations"] == 0 and stats[var]["overflow_queries"] == 0, stats[var]
     ctx.set_option("i8_wide", 1)
     ctx.set_option("i8_pipe", 1)
-    ctx.set_option("i8_waves8", 1)
+    ctx.set_option("i8_waves8", 0)
+    ctx.set_option("i8_defer", 0)
     ctx.set_option("path", 0)
-    for var in (1, 2, 3):
+    for var in range(1, len(variants)):
         assert np.array_equal(res[0][0], res[var][0]) and np.array_equal(res[0][1].view(np.uint32), res[var][1].view(np.uint32)), var
         assert stats[0]["candidates"] == stats[var]["candidates"], var
         assert stats[var]["i8_stage1_tiles"] > 0, stats[var]       # some values passed the hi-plane test and were finished exactly

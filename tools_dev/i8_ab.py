@@ -15,9 +15,10 @@ q = torch.from_numpy(nvdb_amd.synth_rows_f32(20240614, 0, 4 * B, d)).to(dev)
 oi = torch.empty((B, K), dtype=torch.int64, device=dev); os_ = torch.empty((B, K), dtype=torch.float32, device=dev)
 ref = None
 for rnd in range(3):
-    for pipe, w8 in ((1, 1), (1, 0), (0, 0)):
+    for pipe, w8, defer in ((1, 0, 0), (1, 0, 1), (0, 0, 0)):
         ctx.set_option("i8_pipe", pipe)
         ctx.set_option("i8_waves8", w8)
+        ctx.set_option("i8_defer", defer)
         strm = torch.cuda.current_stream().cuda_stream
         for i in range(2): ctx.search_batch_dev(q[i * B:(i + 1) * B].data_ptr(), B, K, oi.data_ptr(), os_.data_ptr(), strm)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -27,5 +28,5 @@ for rnd in range(3):
         got = (oi.cpu().numpy().copy(), os_.cpu().numpy().copy())
         if ref is None: ref = got
         same = np.array_equal(ref[0], got[0]) and np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32))
-        print(f"round {rnd} i8_pipe={pipe} i8_waves8={w8}: {el * 1e3:.3f} ms per pass = {B / el:.0f} queries/s = {2.0 * B * n * d / el / 1e12:.0f} TOP/s algorithmic; "
+        print(f"round {rnd} i8_pipe={pipe} i8_waves8={w8} i8_defer={defer}: {el * 1e3:.3f} ms per pass = {B / el:.0f} queries/s = {2.0 * B * n * d / el / 1e12:.0f} TOP/s algorithmic; "
               f"stage1 {st['i8_stage1_tiles']} stage2 blocks {st['i8_stage2_blocks']} candidates {st['candidates']}; same results as the first run: {same}", flush=True)
