@@ -40,7 +40,8 @@ uint32_t nvdb_permuted_tile(uint32_t g, uint32_t n_tiles);
 
 /* The same for the int8 two-stage kernel (filter_i8w_kernel<768,2>, int8 d=768 corpus, nq > 128): stamped builds of the
  * production loop (variant 0) and of its timing-only ablations 1 = no stage 2 (the lo-plane pass never runs),
- * 2 = no stage-1 test either (stream + hi-plane MFMAs only), 3 = 2 + no per-tile barrier; 10 = the software-pipelined build
+ * 2 = no stage-1 test either (stream + hi-plane MFMAs only), 3 = 2 + no per-tile barrier; 20 / 22 / 24 = the default build (filter_i8p_kernel, first-stage
+ * survivors logged), its test without logging, logging entered and left at once; 10 = the software-pipelined build with the in-loop second stage
  * (filter_i8p_kernel), 11 = its structure alone, 12 = test without rare path.  out[0..3] as above, out[4], out[5] = rare-path
  * entries and lo-plane MFMA blocks per launch, out[6], out[7] = mean and longest tile-loop duration of a workgroup in us (out must hold 8 floats).
  * Developer option "debug_rows" (nvdb_hip_set_option, this build only): the launches cover rows [0, debug_rows) instead of the corpus. */

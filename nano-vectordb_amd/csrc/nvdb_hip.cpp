@@ -886,12 +886,17 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // chunk i covers (growth-1) x the rows seen before it.  fp16: 8 (flat between 4 and 8).  int8 batches > 128: 3 --
   // tighter thresholds earlier mean fewer tiles for which the two-stage kernel needs the lo plane, and a tile costs
   // what its slowest wave costs (profiles/r01d_i8_growth_sweep.txt)
-  uint64_t growth = c->opt_growth > 0 ? static_cast<uint64_t>(c->opt_growth) : (i8_two_stage(c) && nq > 128 ? 3u : 8u);
+  // (with the first-stage survivors finished after the stream a flagged value costs little: 6 and a 1024-tile bootstrap on big
+  // corpora, profiles/r02_i8_boot_growth_sweep.txt; the in-loop second stage wants 3)
+  const bool i8_big = i8_two_stage(c) && nq > 128;
+  const bool i8_log = i8_big && c->opt_i8_pipe && !c->opt_i8_defer && !c->opt_i8_waves8 && c->n >= 64ull * FILTER_ROWS * 1024;
+  uint64_t growth = c->opt_growth > 0 ? static_cast<uint64_t>(c->opt_growth) : (i8_log ? 6u : i8_big ? 3u : 8u);
   if (k_wide) growth = std::max<uint64_t>(2, std::min<uint64_t>(growth, cap / (3ull * k_eff)));     // k * (growth - 1) + k + band <= cap
   // T tile maxima with T >= 8k: their k-th largest is then close to the k-th best of the 32*T rows (with T == k it
   // would be the smallest tile maximum, a uselessly weak threshold)
   uint32_t boot_tiles = std::max<uint32_t>(64u, 8u * k_eff);
   if (c->opt_boot_tiles > 0) boot_tiles = std::max<uint32_t>(boot_tiles, std::min<uint32_t>(static_cast<uint32_t>(c->opt_boot_tiles), cap));
+  else if (i8_log && !k_wide) boot_tiles = std::max<uint32_t>(boot_tiles, std::min<uint32_t>(1024u, cap));
   const uint32_t boot_rows = FILTER_ROWS * boot_tiles;
   const bool mfma_boot = c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
                          boot_rows / FILTER_ROWS <= cap &&
@@ -1584,25 +1589,28 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
       case 1: NVDB_CLK_I8(1) break;
       case 2: NVDB_CLK_I8(2) break;
       case 3: NVDB_CLK_I8(3) break;
-#define NVDB_CLK_I8P(V)                                                                                                          \
+#define NVDB_CLK_I8P(V, DF)                                                                                                      \
       {                                                                                                                          \
-        constexpr size_t ldsp = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + 4 * 256) + 16 * 768;                             \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_i8p_kernel<768, true, true, 6, V>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsp))); \
+        constexpr size_t ldsp = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + 4 * 256) + (DF ? 16 * 768 : 0);                  \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_i8p_kernel<768, true, true, 6, V, 4, DF>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsp))); \
         for (uint32_t r = 0; r < burst; ++r) {                                                                                   \
           HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, prog_bytes, c->stream));                                                     \
-          filter_i8p_kernel<768, true, true, 6, V><<<nwg, 256, ldsp, c->stream>>>(                                               \
+          filter_i8p_kernel<768, true, true, 6, V, 4, DF><<<nwg, 256, ldsp, c->stream>>>(                                               \
               filter_rows_i8(c), filter_scales_i8(c), 0, n_al, qhi, qlo, nq, QT, static_cast<const float*>(c->thr.p),            \
               static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<const float*>(c->qdelta.p), \
               static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap, I8W_TILE_ROWS), static_cast<uint32_t*>(c->prog.p),    \
               static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), static_cast<uint32_t*>(c->misc.p) + 4); \
         }                                                                                                                        \
       }
-      case 10: NVDB_CLK_I8P(0) break;             // the software-pipelined production build, stamped
-      case 11: NVDB_CLK_I8P(1) break;             // ... its structure alone: no test, no rare path
-      case 12: NVDB_CLK_I8P(2) break;             // ... test in the MFMA shadow, rare path never taken
-      case 13: NVDB_CLK_I8P(3) break;             // ... rare path, deferred values never consumed
-      case 14: NVDB_CLK_I8P(4) break;             // ... rare path entered and left at once
-      case 15: NVDB_CLK_I8P(5) break;             // ... production loop, cycles inside rare_path / consume_slots (wave 0 of every workgroup)
+      case 10: NVDB_CLK_I8P(0, true) break;             // the software-pipelined production build, stamped
+      case 11: NVDB_CLK_I8P(1, true) break;             // ... its structure alone: no test, no rare path
+      case 12: NVDB_CLK_I8P(2, true) break;             // ... test in the MFMA shadow, rare path never taken
+      case 13: NVDB_CLK_I8P(3, true) break;             // ... rare path, deferred values never consumed
+      case 14: NVDB_CLK_I8P(4, true) break;             // ... rare path entered and left at once
+      case 15: NVDB_CLK_I8P(5, true) break;             // ... production loop, cycles inside rare_path / consume_slots (wave 0 of every workgroup)
+      case 20: NVDB_CLK_I8P(0, false) break;         // the default build (first-stage survivors logged, finished after the stream), stamped
+      case 22: NVDB_CLK_I8P(2, false) break;         // ... test, nothing logged
+      case 24: NVDB_CLK_I8P(4, false) break;         // ... logging entered and left at once
       default: return fail(c, NVDB_ERR_INVALID, "debug: unknown variant");
     }
     HIPCHK(c, hipGetLastError());
