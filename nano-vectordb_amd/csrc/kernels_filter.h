@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__
 // states separate the last MFMA from the first VALU read of the accumulators.
 // ------------------------------------------------------------------------------------------------
 typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 #define NVDB_MFMA_F16_ZERO_A(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b))
 #define NVDB_MFMA_F16_ZERO_V(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b))
@@ -134,6 +135,10 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
 
 // One survivor of the filter, logged by the wave that found it (16 bytes, one dwordx4 store).
 struct Hit { float score; uint32_t row; uint32_t qid; uint32_t pad; };
+// int8: bound on the L1 norm of a query's hi plane (prep_q8_kernel keeps it): |<row, hi>| <= 128 * I8_HI_L1_MAX < 2^23, the range in
+// which an int32 accumulator started at I8_ACC_BIAS (the bits of 2^23 as a float) reads, as a float, 2^23 + H for H >= 0
+constexpr uint32_t I8_HI_L1_MAX = 65500;
+constexpr int I8_ACC_BIAS = 0x4B000000;
 constexpr uint32_t FILTER_LOGCAP = 4096;           // entries per wave and launch (64 KB of log per wave; typical use: < 100)
 
 // where the logged survivors go when the wave has finished its stream
@@ -923,7 +928,31 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
   mx = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
   ss = (red_ss[0] + red_ss[1]) + (red_ss[2] + red_ss[3]);
   const int tmax = 127 << lo_bits, half = 1 << (lo_bits - 1);   // lo_bits = 7: 15-bit queries, |t| <= 16256
-  const float sq = (mx > 0.f && mx < 3.0e38f) ? mx / static_cast<float>(tmax) : 1.f;
+  const float sq0 = (mx > 0.f && mx < 3.0e38f) ? mx / static_cast<float>(tmax) : 1.f;
+  const float isq0 = 1.0f / sq0;
+  float sq_adj = 1.f;
+  // |H| = |<row, hi plane>| must stay below 2^23 for the biased accumulators of filter_i8p_kernel (I8_HI_L1_MAX * 128 < 2^23).
+  // Only a query with nearly all components at full magnitude exceeds that (mean |hi| > 84 at d = 768): it is quantised
+  // more coarsely (the error terms below follow sq).
+  if (static_cast<uint64_t>(dim) * 127u > I8_HI_L1_MAX) {
+    __shared__ uint32_t red_l1[4];
+    uint32_t l1 = 0;
+    for (uint32_t i = tid; i < dim; i += 256) {
+      int t = static_cast<int>(rintf(src[i] * isq0));
+      t = t > tmax ? tmax : (t < -tmax ? -tmax : t);
+      const int hi = (t + half) >> lo_bits;
+      l1 += static_cast<uint32_t>(hi < 0 ? -hi : hi);
+    }
+    for (int o = 32; o > 0; o >>= 1) l1 += __shfl_xor(l1, o);
+    if ((tid & 63) == 0) red_l1[tid >> 6] = l1;
+    __syncthreads();
+    l1 = (red_l1[0] + red_l1[1]) + (red_l1[2] + red_l1[3]);
+    if (l1 > I8_HI_L1_MAX - dim) {                 // (- dim: every |hi| may round up by one at the coarser scale)
+      const float shrink = static_cast<float>(l1) / static_cast<float>(I8_HI_L1_MAX - dim) * 1.001f;
+      sq_adj = shrink;
+    }
+  }
+  const float sq = sq0 * sq_adj;
   const float isq = 1.0f / sq;
   uint32_t lo2 = 0;                               // sum of lo^2 (exact: <= dim * 4096)
   for (uint32_t i = tid; i < dim; i += 256) {
@@ -954,6 +983,8 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
 
 #define NVDB_MFMA_I8_ZERO(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b))
 #define NVDB_MFMA_I8_ACC(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
+// first k-step of a block whose accumulators start at a constant (16 VGPRs holding it: srcC and vDst share a register class)
+#define NVDB_MFMA_I8_FROM(acc, a, b, c0) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c0))
 
 // BOOT = true: bootstrap build (see filter_f16_kernel VAR 7): best (score,row) per tile and query -> cand lists
 // (hitlog then points at the candidate lists, aux is their stride).
@@ -1598,6 +1629,17 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
   }
 #pragma unroll
   for (int f = 0; f < NB * KSTEPS; ++f) asm volatile("" ::"a"(bq[f]));
+  // !DEFER: the accumulators start at I8_ACC_BIAS, the bits of 2^23 as a float.  |H| < 2^23 (I8_HI_L1_MAX), so the int32 sum read
+  // AS A FLOAT is 2^23 + H for H >= 0 and 2^23 + H / 2 for H < 0: the first-stage test needs no int -> float conversion, one v_fma
+  // per value does it (32 values: 32 fma + 16 max3 instead of 32 cvt + 32 mul + 16 max3; the packed v_pk_add / v_pk_mul pair was
+  // slower than the conversions, profiles/r02g_i8_biased_ab.txt).  Row scales are >= 0 here (a corpus with a negative one takes the DEFER build), so a
+  // negative H only yields a negative value -- halved, i.e. never smaller than the true one: no flag is lost.
+  constexpr bool BIASED = !DEFER;
+  intx16 bias0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bias0[r] = I8_ACC_BIAS;
+  if constexpr (BIASED) asm volatile("" : "+v"(bias0));
+  auto hval = [&](int bits) -> int { return BIASED ? bits - I8_ACC_BIAS : bits; };
   uint32_t qid[NB];
   float thr_s[NB], t1q[NB], inv_s[NB];
   const float lo_unit = __builtin_bit_cast(float, (127u - sa.lo_bits) << 23);   // 2^-lo_bits: the first stage compares H alone
@@ -1692,7 +1734,12 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
   };
 
   intx16 acc0[NB], acc1[NB];                       // row block 0 / 1 of the tile in flight
-  float scv[16];                                   // row scales of the block under test
+  // row scales of the block under test.  DEFER: one set, re-read from LDS at the top of each half.  Otherwise two: [0] block 0 and
+  // [1] block 1 of the current tile, both read in the tile's second half -- block 1 is tested during the NEXT tile's first half,
+  // which then touches nothing of the previous tile's LDS stage: its buffer can be refilled right after barrier A, and barrier B goes.
+  float scv2[DEFER ? 1 : 2][16];
+  float scc2[DEFER ? 1 : 2][16];                   // biased build: -2^23 * scale, the constant of the test's v_fma
+  float (&scv)[16] = scv2[0];
   float mx[NB][4];                                 // running max of H * scale per query block and group of 4 accumulator registers
   float4_t ar[RING];
 
@@ -1700,24 +1747,44 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
   auto read_a = [&](const char* stage, int s, int mb) -> float4_t {
     return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256 + mb * FILTER_ROWS * ROW_BYTES);
   };
-  auto load_scales = [&](const char* stage, int mb) {
+  auto load_scales = [&](const char* stage, int mb, float (&dst)[16]) {
     const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + (wave % SC_COPIES) * 256);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(sc_lds + 32 * mb + 8 * j + 4 * hsel);
-      scv[4 * j] = v.x; scv[4 * j + 1] = v.y; scv[4 * j + 2] = v.z; scv[4 * j + 3] = v.w;
+      dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w;
+    }
+    if constexpr (!DEFER) {
+      float (&dc)[16] = (&dst == &scv2[0]) ? scc2[0] : scc2[DEFER ? 0 : 1];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dc[i] = dst[i] * -8388608.f;
     }
   };
   // Stage-1 test of a block (32 values: query block v / 16, accumulator register v % 16), software-pipelined over the MFMA
   // slots so that the (at most 3) VALU instructions behind one MFMA never depend on each other: slot j converts the values
   // of step j, multiplies those of step j - 1 by their row scales and folds those of step j - 2 into the running maxima.
   float tc[NV], tm[NV];
-  auto test_step = [&](const intx16 (&a)[NB], int j, int vps) {
+  auto test_step = [&](const intx16 (&a)[NB], const float (&sc)[16], int j, int vps) {
     if constexpr (VAR == 1) return;
+    if constexpr (BIASED) {
+      // one v_fma per value: (2^23 + H) * scale - 2^23 * scale = H * scale, rounded once like float(H) * scale (the constant is
+      // exact: a power of two times the scale); slot j multiplies the values of step j, folds those of step j - 1
+      const float (&scc)[16] = (&sc == &scv2[0]) ? scc2[0] : scc2[BIASED ? 1 : 0];
+#pragma unroll
+      for (int v = j * vps; v < (j + 1) * vps; ++v)
+        if (v >= 0 && v < NV) {
+          const int b0 = a[v / 16][v % 16];                                  // (a copy: bit_cast of a vector ELEMENT reads element 0)
+          tm[v] = __builtin_fmaf(__builtin_bit_cast(float, b0), sc[v % 16], scc[v % 16]);
+        }
+#pragma unroll
+      for (int v = (j - 1) * vps; v < j * vps; ++v)
+        if (v >= 0 && v < NV && (v & 1)) mx[v / 16][(v % 16) / 4] = vmax3(mx[v / 16][(v % 16) / 4], tm[v - 1], tm[v]);
+      return;
+    }
 #pragma unroll
     for (int v = j * vps; v < (j + 1) * vps; ++v) if (v >= 0 && v < NV) tc[v] = static_cast<float>(a[v / 16][v % 16]);
 #pragma unroll
-    for (int v = (j - 1) * vps; v < j * vps; ++v) if (v >= 0 && v < NV) tm[v] = tc[v] * scv[v % 16];
+    for (int v = (j - 1) * vps; v < j * vps; ++v) if (v >= 0 && v < NV) tm[v] = tc[v] * sc[v % 16];
 #pragma unroll
     for (int v = (j - 2) * vps; v < (j - 1) * vps; ++v) if (v >= 0 && v < NV && (v & 1)) mx[v / 16][(v % 16) / 4] = vmax3(mx[v / 16][(v % 16) / 4], tm[v - 1], tm[v]);
   };
@@ -1827,7 +1894,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
 
   // DEFER = false: log the values of a tested block that pass the first stage -- row scale, row, query, H -- for the exact
   // finish after the stream.  Per flagged group of 4 accumulator registers one ballot per value; lanes compact into the log.
-  auto rare_log = [&](const intx16 (&a)[NB], uint32_t row0, int mb) {
+  auto rare_log = [&](const intx16 (&a)[NB], const float (&sc)[16], uint32_t row0, int mb) {
     ++n_stage1;
     if constexpr (VAR == 4) return;
 #pragma unroll
@@ -1838,12 +1905,12 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
-          const bool hit = static_cast<float>(a[nb][r]) * scv[r] >= t1q[nb];
+          const bool hit = static_cast<float>(hval(a[nb][r])) * sc[r] >= t1q[nb];
           const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
           if (m) {
             const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
             if (hit && idx < FILTER_LOGCAP)
-              mylog[idx] = Hit{scv[r], row0 + 32u * mb + (r & 3) + 8 * (r >> 2) + 4 * hsel, qid[nb], static_cast<uint32_t>(a[nb][r])};
+              mylog[idx] = Hit{sc[r], row0 + 32u * mb + (r & 3) + 8 * (r >> 2) + 4 * hsel, qid[nb], static_cast<uint32_t>(hval(a[nb][r]))};
             wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
           }
         }
@@ -1866,7 +1933,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     const char* stage = smem + (t % NSTAGE) * STAGE_BYTES;
     const char* prev_stage = smem + ((t + NSTAGE - 1) % NSTAGE) * STAGE_BYTES;
     if (!wave_has_queries) {
-      __builtin_amdgcn_s_barrier();                                        // B
+      if constexpr (DEFER) __builtin_amdgcn_s_barrier();                   // B
 #pragma unroll
       for (int i = 0; i < PPW; ++i) issue_piece(next_row0, next_buf, i);
       issue_scales(next_row0, next_buf);
@@ -1875,10 +1942,17 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     // Behind every MFMA at most one value of the other block's test (slots W0 .. W0 + 31 of the half's 2 KSTEPS MFMAs:
     // <= 3 VALU instructions inside the MFMA's 24 free issue cycles).  The A-fragment ring is primed per half: keeping it
     // alive across the rare path between the halves costs more registers than the file has.
-    constexpr int NSLOT = NB * KSTEPS, W0 = NB == 1 ? (NSLOT / 6 < 4 ? NSLOT / 6 : 4) : (NSLOT / 4 < 8 ? NSLOT / 4 : 8), VPS = (NV + NSLOT - W0 - 4) / (NSLOT - W0 - 3);   // values per slot: 1 at d = 768
-    static_assert(VPS >= 1 && W0 + (NV + VPS - 1) / VPS + 1 <= NSLOT - 2 && (VPS == 1 || VPS % 2 == 0), "the three test stages end before the half's last MFMA");
+    constexpr int NUNIT = NV;                                              // test units: values
+    constexpr int NSLOT = NB * KSTEPS, W0 = NB == 1 ? (NSLOT / 6 < 4 ? NSLOT / 6 : 4) : (NSLOT / 4 < 8 ? NSLOT / 4 : 8), VPS = (NUNIT + NSLOT - W0 - 4) / (NSLOT - W0 - 3);   // units per slot: 1 at d = 768
+    static_assert(VPS >= 1 && W0 + (NUNIT + VPS - 1) / VPS + 1 <= NSLOT - 2 && (VPS == 1 || VPS % 2 == 0 || BIASED), "the three test stages end before the half's last MFMA");
+    // LDS-DMA issue of tile t+2.  DEFER: all of it in the second half, behind barrier B.  Otherwise spread over both halves (one
+    // piece costs ~60 issue cycles; beside the second half's MFMAs, test and ring reads a wave has room for half of them).
+    constexpr int HP = DEFER ? 0 : PPW / 2;                                // pieces issued in the first half
+    constexpr int STEP1 = HP ? KSTEPS / HP : 1, STEP2 = KSTEPS / (PPW - HP);
+    static_assert(DEFER || (PPW % 2 == 0 && KSTEPS % (PPW / 2) == 0), "pieces spread evenly over the k-steps of both halves");
     // ---- first half: block 0 of tile t  ||  test of block 1 of tile t-1 (t == 0: garbage, tested and ignored) ----------
-    load_scales(prev_stage, 1);
+    if constexpr (DEFER) load_scales(prev_stage, 1, scv2[0]);
+    const float (&sc_first)[16] = scv2[DEFER ? 0 : 1];   // (DEFER: the one set)
     reset_max();
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(stage, s, 0);
@@ -1888,24 +1962,29 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
       const float4_t av = ar[s % RING];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        if (s == 0) NVDB_MFMA_I8_ZERO(acc0[nb], av, bq[nb * KSTEPS]);
+        if (s == 0) { if constexpr (BIASED) NVDB_MFMA_I8_FROM(acc0[nb], av, bq[nb * KSTEPS], bias0); else NVDB_MFMA_I8_ZERO(acc0[nb], av, bq[nb * KSTEPS]); }
         else NVDB_MFMA_I8_ACC(acc0[nb], av, bq[nb * KSTEPS + s]);
         const int w = NB * s + nb;
-        test_step(acc1, w - W0, VPS);
+        test_step(acc1, sc_first, w - W0, VPS);
         if (w == NSLOT - 1) combine_flags();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (HP > 0) {
+        if (s % STEP1 == STEP1 - 1) issue_piece(next_row0, next_buf, s / STEP1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     young_loads = 0;
     if ((VAR == 0 || VAR >= 3) && t > 0 && any_flag()) {
       const uint64_t r0 = VAR == 5 ? __builtin_amdgcn_s_memtime() : 0;
-      if constexpr (DEFER) young_loads = rare_path(acc1, prev_stage, tile_row0(t - 1), 1); else rare_log(acc1, tile_row0(t - 1), 1);
+      if constexpr (DEFER) young_loads = rare_path(acc1, prev_stage, tile_row0(t - 1), 1); else rare_log(acc1, sc_first, tile_row0(t - 1), 1);
       if constexpr (VAR == 5) rare_acc += __builtin_amdgcn_s_memtime() - r0;
     }
     if constexpr (VAR == 1 || VAR == 2) { asm volatile("" ::"v"(flagv)); }   // keep this half's test alive
-    __builtin_amdgcn_s_barrier();                                          // B: nobody reads the stage of tile t-1 any more
+    if constexpr (DEFER) __builtin_amdgcn_s_barrier();                     // B: nobody reads the stage of tile t-1 any more
     // ---- second half: block 1 of tile t  ||  loads of tile t+2, test of block 0 of tile t ---------------------------
-    load_scales(stage, 0);
+    load_scales(stage, 0, scv2[0]);
+    if constexpr (!DEFER) load_scales(stage, 1, scv2[1]);                  // block 1's scales: tested in the next tile's first half
     reset_max();
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(stage, s, 1);
@@ -1915,14 +1994,14 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
       const float4_t av = ar[s % RING];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        if (s == 0) NVDB_MFMA_I8_ZERO(acc1[nb], av, bq[nb * KSTEPS]);
+        if (s == 0) { if constexpr (BIASED) NVDB_MFMA_I8_FROM(acc1[nb], av, bq[nb * KSTEPS], bias0); else NVDB_MFMA_I8_ZERO(acc1[nb], av, bq[nb * KSTEPS]); }
         else NVDB_MFMA_I8_ACC(acc1[nb], av, bq[nb * KSTEPS + s]);
         const int w = NB * s + nb;
-        test_step(acc0, w - W0, VPS);
+        test_step(acc0, scv2[0], w - W0, VPS);
         if (w == NSLOT - 1) combine_flags();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (s % (KSTEPS / PPW) == KSTEPS / PPW - 1) issue_piece(next_row0, next_buf, s / (KSTEPS / PPW));
+      if (s % STEP2 == STEP2 - 1) issue_piece(next_row0, next_buf, HP + s / STEP2);
       if (s == 0) issue_scales(next_row0, next_buf);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1934,7 +2013,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     }
     if ((VAR == 0 || VAR >= 3) && any_flag()) {
       const uint64_t r0 = VAR == 5 ? __builtin_amdgcn_s_memtime() : 0;
-      if constexpr (DEFER) rare_path(acc0, stage, tile_row0(t), 0); else rare_log(acc0, tile_row0(t), 0);
+      if constexpr (DEFER) rare_path(acc0, stage, tile_row0(t), 0); else rare_log(acc0, scv2[0], tile_row0(t), 0);
       if constexpr (VAR == 5) rare_acc += __builtin_amdgcn_s_memtime() - r0;
     }
     pend_old = pend_mask;                                                  // everything deferred during this tile: due at the end of the next
@@ -1943,13 +2022,13 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
   if (wave_has_queries) {                          // block 1 of the last tile
     const char* last_stage = smem + ((NT - 1) % NSTAGE) * STAGE_BYTES;
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    load_scales(last_stage, 1);
+    load_scales(last_stage, 1, scv2[0]);
     reset_max();
 #pragma unroll
-    for (int j = 0; j < NV + 2; ++j) test_step(acc1, j, 1);
+    for (int j = 0; j < NV + 2; ++j) test_step(acc1, scv2[0], j, 1);       // (biased build: NV / 2 + 2 of them do something)
     combine_flags();
     if (pend_mask) consume_slots(pend_mask, 0);
-    if ((VAR == 0 || VAR >= 3) && any_flag()) { if constexpr (DEFER) rare_path(acc1, last_stage, tile_row0(NT - 1), 1); else rare_log(acc1, tile_row0(NT - 1), 1); }
+    if ((VAR == 0 || VAR >= 3) && any_flag()) { if constexpr (DEFER) rare_path(acc1, last_stage, tile_row0(NT - 1), 1); else rare_log(acc1, scv2[0], tile_row0(NT - 1), 1); }
     if (pend_mask) consume_slots(pend_mask, 0);
   }
   if constexpr (STAMP) {
@@ -2050,7 +2129,9 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const void* __restric
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     float nrm = sqrtf(ss) * 1.0001f;
     if constexpr (DT == DT_I8) {
-      nrm *= fabsf(scales[r]);
+      const float sc = scales[r];
+      nrm *= fabsf(sc);
+      if (!(sc >= 0.f) && lane == 0) out_bits[1] = 1u;      // a negative (or NaN) row scale: the biased-accumulator test assumes none
     }
     wmax = fmaxf(wmax, nrm);
   }

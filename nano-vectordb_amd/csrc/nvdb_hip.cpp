@@ -63,6 +63,7 @@ struct nvdb_hip_ctx {
   uint32_t dim = 0, dtype = 0;
   uint64_t row_base = 0;
   float max_norm = 0.f;
+  bool i8_scales_signed = false;                   // int8 corpus with a negative or NaN row scale: the in-loop second-stage build (no biased accumulators)
   signed char* shadow8 = nullptr;                  // int8 corpus with a dim the kernels are not instantiated for: rows zero-padded to fdim
   float* shadow8_scales = nullptr;                 // ... and its scales in a buffer padded to whole tiles
   _Float16* shadow16 = nullptr;                    // fp16 copy streamed by the MFMA filter (fp32 corpus and/or padded dim)
@@ -196,6 +197,7 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   h = hb[0];
   std::memcpy(&c->max_norm, &h, 4);
+  c->i8_scales_signed = hb[1] != 0;
   // Which dim do the MFMA kernels run at?  fp16 corpus with an instantiated dim: the corpus itself, no copy.
   // fp32 corpus, or fp16 with another dim <= 1536: an fp16 shadow copy, rows zero-padded to the next instantiated
   // dim (skipped when values would overflow a half).  int8: its own instantiations, no shadow.
@@ -619,7 +621,7 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   }
   const bool pipe = (NB == 2) && c->opt_i8_pipe;
   const bool w8 = pipe && c->opt_i8_waves8;
-  const bool defer = c->opt_i8_defer != 0;
+  const bool defer = c->opt_i8_defer != 0 || c->i8_scales_signed;
   const uint32_t smask = static_cast<uint32_t>(c->opt_sync_every - 1), slead = static_cast<uint32_t>(c->opt_sync_lead);
   if (sync) {
     uint32_t* prog = nullptr;
@@ -889,7 +891,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // (with the first-stage survivors finished after the stream a flagged value costs little: 6 and a 1024-tile bootstrap on big
   // corpora, profiles/r02_i8_boot_growth_sweep.txt; the in-loop second stage wants 3)
   const bool i8_big = i8_two_stage(c) && nq > 128;
-  const bool i8_log = i8_big && c->opt_i8_pipe && !c->opt_i8_defer && !c->opt_i8_waves8 && c->n >= 64ull * FILTER_ROWS * 1024;
+  const bool i8_log = i8_big && c->opt_i8_pipe && !c->opt_i8_defer && !c->i8_scales_signed && !c->opt_i8_waves8 && c->n >= 64ull * FILTER_ROWS * 1024;
   uint64_t growth = c->opt_growth > 0 ? static_cast<uint64_t>(c->opt_growth) : (i8_log ? 6u : i8_big ? 3u : 8u);
   if (k_wide) growth = std::max<uint64_t>(2, std::min<uint64_t>(growth, cap / (3ull * k_eff)));     // k * (growth - 1) + k + band <= cap
   // T tile maxima with T >= 8k: their k-th largest is then close to the k-th best of the 32*T rows (with T == k it

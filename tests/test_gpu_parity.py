@@ -277,6 +277,53 @@ def test_int8_two_stage_kernel_with_a_negative_row_scale(ctx, oracle):
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, ids, sc, k, "i8-negscale")
 
 
+@pytest.mark.parametrize("d,nq", [(768, 300), (512, 200)])
+def test_int8_biased_accumulators_at_their_limits(ctx, oracle, d, nq):
+    """The default int8 kernel for batches > 128 starts its accumulators at the bits of 2^23 and reads the sums as floats
+    (kernels_filter.h, I8_ACC_BIAS): exact for 0 <= H < 2^23, monotone (halved) for negative H.  Exercise the edges:
+      * flat queries (every component at full magnitude: the hi plane's L1 norm would reach 768 * 127 > I8_HI_L1_MAX, so
+        prep_q8_kernel quantises them more coarsely), against rows of constant sign at full magnitude (largest |H|);
+      * queries whose every score is negative (negative thresholds, negative H everywhere);
+      * the in-loop second-stage build (no bias) must log the same survivors."""
+    n, k = 150000 + 5, 10
+    base, scales = nvdb_amd.synth_corpus(SEED + 90, 0, n, d, nvdb_amd.DT_I8)
+    base, scales = base.copy(), scales.copy()
+    base[:64] = 127; base[64:128] = -128; base[128:160] = np.where(np.arange(d) % 2 == 0, 127, -127).astype(np.int8)   # extreme rows
+    base[200:20000] = np.abs(base[200:20000].astype(np.int16)).clip(0, 127).astype(np.int8)                             # a block of non-negative rows
+    queries = nvdb_amd.synth_rows_f32(SEED + 91, 0, nq, d)
+    queries[0] = 1.0                                               # flat, positive: H = 127 * L1(hi) against the all-127 rows
+    queries[1] = -1.0                                              # flat, negative: largest H against the all-(-128) rows
+    queries[2] = np.where(np.arange(d) % 2 == 0, 1.0, -1.0)
+    queries[3] = np.sign(queries[3]) * np.float32(3.25)            # flat magnitude, random signs
+    queries[4] = -np.abs(queries[4])                               # against the non-negative block: every score there is negative
+    queries[5] = np.abs(queries[5]) * np.float32(1e-3)
+    ctx.upload_corpus(base, po.DT_I8, scales)
+    ctx.set_option("path", 2)
+    res, stats = {}, {}
+    for var, defer in enumerate((0, 1)):
+        ctx.set_option("i8_defer", defer)
+        res[var] = ctx.search_batch(queries, k)
+        stats[var] = ctx.stats()
+        assert stats[var]["path"] == 2 and stats[var]["bound_violations"] == 0 and stats[var]["overflow_queries"] == 0, stats[var]
+    ctx.set_option("i8_defer", 0)
+    ctx.set_option("path", 0)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+    assert stats[0]["candidates"] == stats[1]["candidates"]
+    _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[0][0], res[0][1], k, f"i8-biased/d{d}")
+    # all-negative scores: a corpus of non-negative rows only, a batch of non-positive queries
+    sub = np.ascontiguousarray(base[200:20000])
+    ssc = np.ascontiguousarray(np.abs(scales[200:20000]))
+    qn = -np.abs(nvdb_amd.synth_rows_f32(SEED + 92, 0, 200, d))
+    ctx.upload_corpus(sub, po.DT_I8, ssc)
+    ctx.set_option("path", 2)
+    ids, sc = ctx.search_batch(qn, k)
+    st = ctx.stats()
+    ctx.set_option("path", 0)
+    assert st["path"] == 2 and st["bound_violations"] == 0, st
+    assert np.all(sc < 0)
+    _check_against_oracle(oracle, sub, po.DT_I8, ssc, qn, ids, sc, k, f"i8-biased-negative/d{d}")
+
+
 def test_filter_path_scaled_and_skewed_queries(ctx, oracle):
     """Query scale must not matter (per-query power-of-two prescale), nor heavy-tailed elements."""
     n, d, nq, k = 100000, 768, 48, 10
