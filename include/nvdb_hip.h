@@ -168,7 +168,7 @@ nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint3
 /* Tunables (defaults are what bench.py measures; the table with meanings is in INTEGRATION.md section 4b):
  * "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "chunk_growth", "cand_cap", "min_filter_batch", "mfma_boot",
  * "mfma16", "waves8", "sibling_sync", "sync_every", "sync_lead", "tile_permute", "f32_shadow" (set before the upload),
- * "i8_wide", "i8_pipe", "i8_waves8", "i8_lo_bits", "boot_tiles", "xcd_balance", "rescore8", "refine_v2", "refine_pinned" (reference CUDA_PINNED: pinned host staging in nvdb_hip_refine_l2_topk), "largek_budget_mb" (HBM for the any-k path's score matrix), "time_kernels" (1: start / stop events attached to every launch of the dominant
+ * "i8_wide", "i8_pipe", "i8_defer", "i8_waves8", "i8_lo_bits", "boot_tiles", "xcd_balance", "rescore8", "refine_v2", "refine_pinned" (reference CUDA_PINNED: pinned host staging in nvdb_hip_refine_l2_topk), "largek_budget_mb" (HBM for the any-k path's score matrix), "time_kernels" (1: start / stop events attached to every launch of the dominant
  * kernel).  Unknown key -> NVDB_ERR_INVALID. */
 nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* ctx, const char* key, int64_t value);
 
