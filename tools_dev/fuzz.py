@@ -29,6 +29,11 @@ for ci in range(cases):
     if rs.rand() < 0.2: opts["chunk_growth"] = int(rs.choice([2, 3, 16]))
     if rs.rand() < 0.15: opts["mfma_boot"] = 0
     if rs.rand() < 0.15: opts["sibling_sync"] = 0
+    if rs.rand() < 0.2: opts["xcd_balance"] = 0
+    if tag == "i8":
+        if rs.rand() < 0.25: opts["i8_defer"] = 1
+        if rs.rand() < 0.2: opts["i8_lo_bits"] = int(rs.choice([3, 5, 6]))
+        if rs.rand() < 0.2: opts["boot_tiles"] = int(rs.choice([128, 512, 1024]))
     for k_, v in opts.items(): ctx.set_option(k_, v)
     try:
         ctx.set_option("path", 0); ai, asc = ctx.search_batch(q, k); st = ctx.stats()
@@ -40,7 +45,7 @@ for ci in range(cases):
             ok = ok and np.array_equal(ei[qi], oi[0]) and np.array_equal(es[qi].view(np.uint32), osc.view(np.uint32)[0]) if False else ok and np.array_equal(ei[qi], oi[0]) and np.array_equal(es[qi].view(np.uint32), os_[0].view(np.uint32))
     except Exception as e:
         ok = False; st = {"error": str(e)}
-    for k_ in opts: ctx.set_option(k_, {"tile_permute": 1, "chunk_growth": 0, "mfma_boot": 1, "sibling_sync": 1}[k_])
+    for k_ in opts: ctx.set_option(k_, {"tile_permute": 1, "chunk_growth": 0, "mfma_boot": 1, "sibling_sync": 1, "xcd_balance": 1, "i8_defer": 0, "i8_lo_bits": 7, "boot_tiles": 0}[k_])
     ctx.set_option("path", 0)
     if not ok:
         fails += 1
