@@ -1947,18 +1947,28 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     static_assert(VPS >= 1 && W0 + (NUNIT + VPS - 1) / VPS + 1 <= NSLOT - 2 && (VPS == 1 || VPS % 2 == 0 || BIASED), "the three test stages end before the half's last MFMA");
     // LDS-DMA issue of tile t+2.  DEFER: all of it in the second half, behind barrier B.  Otherwise spread over both halves (one
     // piece costs ~60 issue cycles; beside the second half's MFMAs, test and ring reads a wave has room for half of them).
-    constexpr int HP = DEFER ? 0 : PPW / 2;                                // pieces issued in the first half
-    constexpr int STEP1 = HP ? KSTEPS / HP : 1, STEP2 = KSTEPS / (PPW - HP);
-    static_assert(DEFER || (PPW % 2 == 0 && KSTEPS % (PPW / 2) == 0), "pieces spread evenly over the k-steps of both halves");
+    constexpr int HP = DEFER ? 0 : PPW / 2;                                // pieces issued in the first half ...
+    constexpr int HP0 = DEFER ? 0 : (HP < 3 ? HP : 3);                     // ... of them in the bubble while the A-fragment ring fills after barrier A
+    constexpr int STEP1 = (HP - HP0) ? KSTEPS / (HP - HP0) : 1, STEP2 = KSTEPS / (PPW - HP);
+    static_assert(DEFER || (PPW % 2 == 0 && KSTEPS % (PPW / 2) == 0 && (HP == HP0 || KSTEPS % (HP - HP0) == 0)), "pieces spread evenly over the k-steps of both halves");
+    // !DEFER: the ring runs through both halves of a tile (the last RING - 1 k-steps of block 0 fetch the first fragments of block 1):
+    // one priming bubble per tile instead of two, and the first LDS-DMA issues of the tile sit inside it.
+    constexpr bool THROUGH = !DEFER;
     // ---- first half: block 0 of tile t  ||  test of block 1 of tile t-1 (t == 0: garbage, tested and ignored) ----------
     if constexpr (DEFER) load_scales(prev_stage, 1, scv2[0]);
     const float (&sc_first)[16] = scv2[DEFER ? 0 : 1];   // (DEFER: the one set)
     reset_max();
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(stage, s, 0);
+    if constexpr (HP0 > 0) {
+#pragma unroll
+      for (int i = 0; i < HP0; ++i) issue_piece(next_row0, next_buf, i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(stage, s + RING - 1, 0);
+      else if constexpr (THROUGH) ar[(s + RING - 1) % RING] = read_a(stage, s + RING - 1 - KSTEPS, 1);
       const float4_t av = ar[s % RING];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
@@ -1969,8 +1979,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
         if (w == NSLOT - 1) combine_flags();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (HP > 0) {
-        if (s % STEP1 == STEP1 - 1) issue_piece(next_row0, next_buf, s / STEP1);
+      if constexpr (HP > HP0) {
+        if (s % STEP1 == STEP1 - 1) issue_piece(next_row0, next_buf, HP0 + s / STEP1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1986,12 +1996,15 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     load_scales(stage, 0, scv2[0]);
     if constexpr (!DEFER) load_scales(stage, 1, scv2[1]);                  // block 1's scales: tested in the next tile's first half
     reset_max();
+    constexpr int R0 = THROUGH ? KSTEPS % RING : 0;                        // ring slot of block 1's first fragment
+    if constexpr (!THROUGH) {
 #pragma unroll
-    for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(stage, s, 1);
+      for (int s = 0; s < RING - 1; ++s) ar[s] = read_a(stage, s, 1);
+    }
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-      if (s + RING - 1 < KSTEPS) ar[(s + RING - 1) % RING] = read_a(stage, s + RING - 1, 1);
-      const float4_t av = ar[s % RING];
+      if (s + RING - 1 < KSTEPS) ar[(R0 + s + RING - 1) % RING] = read_a(stage, s + RING - 1, 1);
+      const float4_t av = ar[(R0 + s) % RING];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         if (s == 0) { if constexpr (BIASED) NVDB_MFMA_I8_FROM(acc1[nb], av, bq[nb * KSTEPS], bias0); else NVDB_MFMA_I8_ZERO(acc1[nb], av, bq[nb * KSTEPS]); }
