@@ -1760,6 +1760,24 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
       for (int i = 0; i < 16; ++i) dc[i] = dst[i] * -8388608.f;
     }
   };
+  // !DEFER: the same in the shadow of the MFMAs -- slot 0 reads the 16 scales of block mb of `stage` into set `set`, the slots from the 6th on
+  // multiply one of them each by -2^23 (the test's v_fma constant).  Block 0's set is filled during the tile's first half (used in
+  // the second), block 1's during the second half (used in the next tile's first half).
+  auto scale_step = [&](const char* stage, int mb, int set, int w) {
+    if constexpr (VAR == 1) return;
+    if (w == 0) {
+      const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + (wave % SC_COPIES) * 256);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(sc_lds + 32 * mb + 8 * j + 4 * hsel);
+        scv2[set][4 * j] = v.x; scv2[set][4 * j + 1] = v.y; scv2[set][4 * j + 2] = v.z; scv2[set][4 * j + 3] = v.w;
+      }
+    }
+    constexpr int NSL = NB * KSTEPS, SW0 = NSL >= 32 ? 6 : 4, SPS = (16 + NSL - SW0 - 1) / (NSL - SW0);   // constants per slot: 1 at d >= 512
+#pragma unroll
+    for (int i = (w - SW0) * SPS; i < (w - SW0 + 1) * SPS; ++i)
+      if (i >= 0 && i < 16) scc2[set][i] = scv2[set][i] * -8388608.f;
+  };
   // Stage-1 test of a block (32 values: query block v / 16, accumulator register v % 16), software-pipelined over the MFMA
   // slots so that the (at most 3) VALU instructions behind one MFMA never depend on each other: slot j converts the values
   // of step j, multiplies those of step j - 1 by their row scales and folds those of step j - 2 into the running maxima.
@@ -1975,6 +1993,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
         if (s == 0) { if constexpr (BIASED) NVDB_MFMA_I8_FROM(acc0[nb], av, bq[nb * KSTEPS], bias0); else NVDB_MFMA_I8_ZERO(acc0[nb], av, bq[nb * KSTEPS]); }
         else NVDB_MFMA_I8_ACC(acc0[nb], av, bq[nb * KSTEPS + s]);
         const int w = NB * s + nb;
+        if constexpr (!DEFER) scale_step(stage, 0, 0, w);
         test_step(acc1, sc_first, w - W0, VPS);
         if (w == NSLOT - 1) combine_flags();
         __builtin_amdgcn_sched_barrier(0);
@@ -1993,8 +2012,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     if constexpr (VAR == 1 || VAR == 2) { asm volatile("" ::"v"(flagv)); }   // keep this half's test alive
     if constexpr (DEFER) __builtin_amdgcn_s_barrier();                     // B: nobody reads the stage of tile t-1 any more
     // ---- second half: block 1 of tile t  ||  loads of tile t+2, test of block 0 of tile t ---------------------------
-    load_scales(stage, 0, scv2[0]);
-    if constexpr (!DEFER) load_scales(stage, 1, scv2[1]);                  // block 1's scales: tested in the next tile's first half
+    if constexpr (DEFER) load_scales(stage, 0, scv2[0]);                   // (!DEFER: block 0's set was filled during the first half)
     reset_max();
     constexpr int R0 = THROUGH ? KSTEPS % RING : 0;                        // ring slot of block 1's first fragment
     if constexpr (!THROUGH) {
@@ -2010,6 +2028,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
         if (s == 0) { if constexpr (BIASED) NVDB_MFMA_I8_FROM(acc1[nb], av, bq[nb * KSTEPS], bias0); else NVDB_MFMA_I8_ZERO(acc1[nb], av, bq[nb * KSTEPS]); }
         else NVDB_MFMA_I8_ACC(acc1[nb], av, bq[nb * KSTEPS + s]);
         const int w = NB * s + nb;
+        if constexpr (!DEFER) scale_step(stage, 1, DEFER ? 0 : 1, w);        // block 1's scales: tested in the next tile's first half
         test_step(acc0, scv2[0], w - W0, VPS);
         if (w == NSLOT - 1) combine_flags();
         __builtin_amdgcn_sched_barrier(0);
