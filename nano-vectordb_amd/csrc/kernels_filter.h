@@ -139,6 +139,8 @@ struct Hit { float score; uint32_t row; uint32_t qid; uint32_t pad; };
 // which an int32 accumulator started at I8_ACC_BIAS (the bits of 2^23 as a float) reads, as a float, 2^23 + H for H >= 0
 constexpr uint32_t I8_HI_L1_MAX = 65500;
 constexpr int I8_ACC_BIAS = 0x4B000000;
+// H * 2^bits for a possibly negative H (a left shift of a negative int is undefined before C++20; the range is checked: |H| < 2^23, bits <= 7)
+__device__ __forceinline__ int shl_i32(int v, uint32_t bits) { return static_cast<int>(static_cast<uint32_t>(v) << bits); }
 constexpr uint32_t FILTER_LOGCAP = 4096;           // entries per wave and launch (64 KB of log per wave; typical use: < 100)
 
 // where the logged survivors go when the wave has finished its stream
@@ -639,6 +641,50 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_f16_m16_kernel(
   uint64_t stamp_c = 0, stamp_r = 0;
   if constexpr (STAMP) { stamp_c = __builtin_amdgcn_s_memtime(); stamp_r = __builtin_amdgcn_s_memrealtime(); }
   const uint32_t xw_t0 = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
+  // 8-wave build: the two waves of a SIMD leave the per-tile barrier together, multiply together and would test together, with
+  // the matrix pipe idle meanwhile.  Waves 4..7 therefore test a tile's accumulators AFTER the next barrier (LATE): their test
+  // runs beside the partner wave's ring priming and first MFMAs, the partner's test beside their last MFMAs.
+  const bool late = (WPB == 8) && (VAR == 0 || VAR == 21) && wave >= 4;
+  float4_t acc[MB][NQB];
+  auto epilogue = [&](uint32_t te) {
+    // "does any of my 32 scores reach its query's threshold": a max tree per query block (v_max3_f32), one subtract
+    // per block, one compare in all -- 23 vector instructions.  (32 compares into SGPR pairs + 32 s_or_b64 cost
+    // ~770 cycles per tile, a quarter of the tile's MFMA time: profiles/r01d_clock_ablation.txt.)
+    float dmax[NQB];
+#pragma unroll
+    for (int nb = 0; nb < NQB; ++nb) {
+      float v[4 * MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * mb + r] = acc[mb][nb][r];
+      float m = vmax3(v[0], v[1], v[2]);
+#pragma unroll
+      for (int x = 3; x + 1 < 4 * MB; x += 2) m = vmax3(m, v[x], v[x + 1]);
+      m = vmax3(m, v[4 * MB - 1], v[4 * MB - 1]);                  // 4*MB is even: one value is left over
+      dmax[nb] = m - thr_s[nb];                      // >= 0 iff m >= thr (a difference of floats never rounds across 0)
+    }
+    const bool any = (NQB == 4 ? vmax3(vmax3(dmax[0], dmax[1], dmax[NQB / 2]), dmax[NQB - 1], dmax[NQB - 1])
+                               : NQB == 2 ? vmax3(dmax[0], dmax[NQB - 1], dmax[NQB - 1]) : dmax[0]) >= 0.f;
+    if (__builtin_amdgcn_ballot_w64(any)) {
+      const uint32_t row0 = tile_phys(te) * TROWS;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NQB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[mb][nb][r];
+            const bool hit = v >= thr_s[nb];
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            if (m) {
+              const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+              if (hit && idx < FILTER_LOGCAP) mylog[idx] = Hit{v * inv_s[nb], row0 + 16 * mb + 4 * g4 + r, qid[nb], 0u};
+              wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
+            }
+          }
+    }
+  };
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
       // wave 0 only; the per-tile barrier holds the other waves back
@@ -655,6 +701,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_f16_m16_kernel(
       for (int i = 0; i < PPW; ++i) issue_piece(next_tile, next_buf, i);
       continue;
     }
+    if (late && t > 0) epilogue(t - 1);
     auto read_a = [&](int u) -> float4_t {        // u = MB*s + mb
       const int s = u / MB, mb = u % MB;
       return *reinterpret_cast<const float4_t*>(stage + (a16 ^ ((s & 3) << 6)) + (s >> 2) * 256 + mb * 16 * ROW_BYTES);
@@ -666,7 +713,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_f16_m16_kernel(
     }
 #pragma unroll
     for (int u = 0; u < RING - 1; ++u) if constexpr (!NO_READ) ar[u] = read_a(u);
-    float4_t acc[MB][NQB];
 #pragma unroll
     for (int u = 0; u < NREAD; ++u) {
       if constexpr (!NO_READ) { if (u + RING - 1 < NREAD) ar[(u + RING - 1) % RING] = read_a(u + RING - 1); }
@@ -692,44 +738,9 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_f16_m16_kernel(
 #pragma unroll
       for (int nb = 0; nb < NQB; ++nb) asm volatile("" : "+v"(acc[mb][nb]));
     if constexpr (NO_EPI) continue;
-    // "does any of my 32 scores reach its query's threshold": a max tree per query block (v_max3_f32), one subtract
-    // per block, one compare in all -- 23 vector instructions.  (32 compares into SGPR pairs + 32 s_or_b64 cost
-    // ~770 cycles per tile, a quarter of the tile's MFMA time: profiles/r01d_clock_ablation.txt.)
-    float dmax[NQB];
-#pragma unroll
-    for (int nb = 0; nb < NQB; ++nb) {
-      float v[4 * MB];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[4 * mb + r] = acc[mb][nb][r];
-      float m = vmax3(v[0], v[1], v[2]);
-#pragma unroll
-      for (int x = 3; x + 1 < 4 * MB; x += 2) m = vmax3(m, v[x], v[x + 1]);
-      m = vmax3(m, v[4 * MB - 1], v[4 * MB - 1]);                  // 4*MB is even: one value is left over
-      dmax[nb] = m - thr_s[nb];                      // >= 0 iff m >= thr (a difference of floats never rounds across 0)
-    }
-    const bool any = (NQB == 4 ? vmax3(vmax3(dmax[0], dmax[1], dmax[NQB / 2]), dmax[NQB - 1], dmax[NQB - 1])
-                               : NQB == 2 ? vmax3(dmax[0], dmax[NQB - 1], dmax[NQB - 1]) : dmax[0]) >= 0.f;
-    if (__builtin_amdgcn_ballot_w64(any)) {
-      const uint32_t row0 = tile_phys(t) * TROWS;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NQB; ++nb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = acc[mb][nb][r];
-            const bool hit = v >= thr_s[nb];
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-            if (m) {
-              const uint32_t idx = wcnt + static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull)));
-              if (hit && idx < FILTER_LOGCAP) mylog[idx] = Hit{v * inv_s[nb], row0 + 16 * mb + 4 * g4 + r, qid[nb], 0u};
-              wcnt += static_cast<uint32_t>(__builtin_popcountll(m));
-            }
-          }
-    }
+    if (!late) epilogue(t);
   }
+  if (late && wave_has_queries) epilogue(NT - 1);
   if constexpr (STAMP) {
     const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c, dr = __builtin_amdgcn_s_memrealtime() - stamp_r;
     if (wave == 0 && lane == 0) {
@@ -1122,7 +1133,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * j + i;
-        fv[r] = static_cast<float>((acc_hi[r] << sa.lo_bits) + acc_lo[r]) * scv[i];
+        fv[r] = static_cast<float>(shl_i32(acc_hi[r], sa.lo_bits) + acc_lo[r]) * scv[i];
       }
     }
     float fmx = vmax3(fv[0], fv[1], fv[2]);
@@ -1327,7 +1338,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
       part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x.w), static_cast<int>(lo.w), part, false);
     }
     part = wave_sum_i32(part);                                             // exact: integer sum
-    const float fv = static_cast<float>((pend_H << sa.lo_bits) + part) * pend_scale;
+    const float fv = static_cast<float>(shl_i32(pend_H, sa.lo_bits) + part) * pend_scale;
     if (fv >= pend_thr) {
       if (lane == 0 && wcnt < FILTER_LOGCAP) mylog[wcnt] = Hit{fv * pend_inv, pend_row, pend_qid, 0u};
       ++wcnt;
@@ -1475,7 +1486,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(lo));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float fv = static_cast<float>((acc[mb][nb][r] << sa.lo_bits) + lo[r]) * scv[mb][r];
+          const float fv = static_cast<float>(shl_i32(acc[mb][nb][r], sa.lo_bits) + lo[r]) * scv[mb][r];
           const bool hit = fv >= thr_s[nb];
           const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
           if (m) {
@@ -1542,7 +1553,7 @@ __device__ __forceinline__ void verify_and_scatter_i8(const Hit* mylog, uint32_t
     part += __builtin_amdgcn_update_dpp(0, part, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
     part += __builtin_amdgcn_update_dpp(0, part, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]: the entry's four lanes hold L
     if (valid && part4 == 0) {
-      const float fv = static_cast<float>((H << a.lo_bits) + part) * __builtin_bit_cast(float, sbits);
+      const float fv = static_cast<float>(shl_i32(H, a.lo_bits) + part) * __builtin_bit_cast(float, sbits);
       if (fv >= thr[qid] * qscale[qid]) {
         const uint32_t slot = atomicAdd(&a.cnt[qid], 1u);
         if (slot < a.cap) a.cand[static_cast<uint64_t>(qid) * a.cap + slot] = Cand{fv * qinv[qid], row};
@@ -1724,7 +1735,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
         part = __builtin_amdgcn_sdot4(static_cast<int>(pend_x[i].w), static_cast<int>(lo.w), part, false);
       }
       part = wave_sum_i32(part);                                           // exact: integer sum
-      const float fv = static_cast<float>((pend_H[i] << sa.lo_bits) + part) * pend_scale[i];
+      const float fv = static_cast<float>(shl_i32(pend_H[i], sa.lo_bits) + part) * pend_scale[i];
       if (fv >= pend_thr[i]) {                     // (a slot given up by the block path carries thr = +inf)
         if (lane == 0 && wcnt < FILTER_LOGCAP) mylog[wcnt] = Hit{fv * pend_inv[i], pend_row[i], pend_qid[i], 0u};
         ++wcnt;
@@ -1897,7 +1908,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
       asm volatile("s_nop 15\n\ts_nop 15" : "+v"(lo));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float fv = static_cast<float>((a[nb][r] << sa.lo_bits) + lo[r]) * scv[r];
+        const float fv = static_cast<float>(shl_i32(a[nb][r], sa.lo_bits) + lo[r]) * scv[r];
         const bool hit = fv >= thr_s[nb];
         const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
         if (m) {
