@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd"))
 import numpy as np, torch, nvdb_amd
 dt = nvdb_amd.DT_I8 if (len(sys.argv) < 2 or sys.argv[1] == "i8") else nvdb_amd.DT_F16
-n, d, B, K = 10_000_000, 768, 1024, 10
+n, d, B, K = 10_000_000, 768, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 10
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 ctx = nvdb_amd.HipContext(0)
@@ -14,7 +14,7 @@ ctx.generate_corpus(20240613, n, d, dt)
 q = torch.from_numpy(nvdb_amd.synth_rows_f32(20240614, 0, 4 * B, d)).to(dev)
 oi = torch.empty((B, K), dtype=torch.int64, device=dev); os_ = torch.empty((B, K), dtype=torch.float32, device=dev)
 ref = None
-growths = (3, 4, 6, 8) if dt == nvdb_amd.DT_I8 else (0, 4, 6, 12, 16)
+growths = (3, 4, 6, 8) if dt == nvdb_amd.DT_I8 else ((0, 4, 6, 12, 16) if B > 128 else (0, 16, 32, 64))
 for rnd in range(2):
     for lb, tiles in (((7, 0), (7, 256), (7, 1024), (6, 0), (5, 0)) if dt == nvdb_amd.DT_I8 else ((7, 0), (7, 256), (7, 1024), (7, 2048))):
         for growth in growths:
