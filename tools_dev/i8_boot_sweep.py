@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd"))
 import numpy as np, torch, nvdb_amd
 dt = nvdb_amd.DT_I8 if (len(sys.argv) < 2 or sys.argv[1] == "i8") else nvdb_amd.DT_F16
-n, d, B, K = 10_000_000, 768, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 10
+n, d, B, K = (int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000), 768, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 10
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 ctx = nvdb_amd.HipContext(0)
