@@ -1575,11 +1575,19 @@ __device__ __forceinline__ void verify_and_scatter_i8(const Hit* mylog, uint32_t
 //   tile t:  barrier A | MFMAs(block 0, tile t)  ||  test(block 1, tile t-1), its rare path | barrier B |
 //                        MFMAs(block 1, tile t)  ||  loads of tile t+2, test(block 0, tile t), its rare path
 //
-// No second accumulator set: block 0's accumulators are tested while block 1's are written and vice versa.  Barrier B
-// is what the overlap costs: block 1 of tile t-1 is tested during tile t, and its rare path still reads that tile's LDS
-// stage, so the loads that overwrite it (tile t+2, same buffer) are issued only after every wave has passed B.
-// The rare path is filter_i8w_kernel's: one flagged value -> deferred exact dot product (v_dot4), several -> lo-plane
-// MFMAs of the block.  Same survivors, same filter scores (test_int8_two_stage_kernel_matches_two_plane_kernel).
+// No second accumulator set: block 0's accumulators are tested while block 1's are written and vice versa.
+//
+// Two builds of the loop (template DEFER; every build logs the same survivors with the same filter scores,
+// test_int8_two_stage_kernel_matches_two_plane_kernel):
+//   DEFER = false, the default: a value that passes the first stage is only LOGGED in the loop (row scale, row, query, H) and
+//     finished exactly after the stream by verify_and_scatter_i8.  Nothing in the loop reads the previous tile's LDS stage
+//     (block 1's row scales are kept in registers), so there is ONE barrier per tile (A), the tile's LDS-DMA issues are spread
+//     over both halves (the first three in the bubble while the fragment ring fills), the ring runs through both halves, and the
+//     accumulators start at the bits of 2^23 so that the test is one v_fma per value (BIASED, see below).
+//   DEFER = true (option i8_defer, and by itself for a corpus with a negative / NaN row scale): the in-loop second stage of
+//     filter_i8w_kernel -- one flagged value -> deferred exact dot product (v_dot4), several -> lo-plane MFMAs of the block.
+//     Barrier B is what it costs: block 1 of tile t-1 is tested during tile t, and its rare path still reads that tile's LDS
+//     stage, so the loads that overwrite it (tile t+2, same buffer) are issued only after every wave has passed B.
 // ------------------------------------------------------------------------------------------------
 // VAR (diagnostic builds, STAMP only; wrong results): 1 = no test and no rare path (the pipelined structure alone), 2 = test but no rare path,
 // 3 = rare path without consuming the deferred values, 4 = rare path entered and left at once; 5 = the production loop (right results) reporting
