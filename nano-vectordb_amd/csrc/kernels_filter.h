@@ -1524,45 +1524,55 @@ __device__ __forceinline__ void verify_and_scatter_i8(const Hit* mylog, uint32_t
   uint32_t n = wcnt;
   if (n > FILTER_LOGCAP) { if (lane == 0) *a.log_overflow = 1u; n = FILTER_LOGCAP; }
   constexpr int CPL = DIM / 64;                      // 16-byte chunks per lane (4 lanes per entry)
+  constexpr int NE = 2;                              // entries per lane group and step: the loads of both are in flight together
   const int part4 = lane & 3;
-  for (uint32_t base = 0; base < n; base += 16) {
-    const uint32_t e = base + (static_cast<uint32_t>(lane) >> 2);
-    bool valid = e < n;
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(mylog + (valid ? e : 0u));
-    // L2-served loads: the entries were written by this wave in this launch
-    const uint32_t sbits = __hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t row = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t qid = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int H = static_cast<int>(__hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    valid = valid && row < a.n_rows;
-    int part = 0;
-    if (valid) {
-      const uint4* xr = reinterpret_cast<const uint4*>(rows + static_cast<uint64_t>(row) * DIM);
-      const uint4* qr = reinterpret_cast<const uint4*>(qlo + static_cast<uint64_t>(qid) * DIM);
-      uint4 x[CPL], y[CPL];
+  for (uint32_t base = 0; base < n; base += 16 * NE) {
+    uint32_t sbits[NE], row[NE], qid[NE];
+    int H[NE], part[NE];
+    bool valid[NE];
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) { x[c] = xr[part4 + 4 * c]; y[c] = qr[part4 + 4 * c]; }
+    for (int j = 0; j < NE; ++j) {
+      const uint32_t e = base + 16u * j + (static_cast<uint32_t>(lane) >> 2);
+      valid[j] = e < n;
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(mylog + (valid[j] ? e : 0u));
+      // L2-served loads: the entries were written by this wave in this launch
+      sbits[j] = __hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      row[j] = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      qid[j] = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      H[j] = static_cast<int>(__hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    uint4 x[NE][CPL], y[NE][CPL];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      valid[j] = valid[j] && row[j] < a.n_rows;
+      const uint4* xr = reinterpret_cast<const uint4*>(rows + static_cast<uint64_t>(valid[j] ? row[j] : 0u) * DIM);
+      const uint4* qr = reinterpret_cast<const uint4*>(qlo + static_cast<uint64_t>(valid[j] ? qid[j] : 0u) * DIM);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { x[j][c] = xr[part4 + 4 * c]; y[j][c] = qr[part4 + 4 * c]; }   // (an invalid slot reads row 0 / query 0: in bounds, unused)
+    }
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      part[j] = 0;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        part = __builtin_amdgcn_sdot4(static_cast<int>(x[c].x), static_cast<int>(y[c].x), part, false);
-        part = __builtin_amdgcn_sdot4(static_cast<int>(x[c].y), static_cast<int>(y[c].y), part, false);
-        part = __builtin_amdgcn_sdot4(static_cast<int>(x[c].z), static_cast<int>(y[c].z), part, false);
-        part = __builtin_amdgcn_sdot4(static_cast<int>(x[c].w), static_cast<int>(y[c].w), part, false);
+        part[j] = __builtin_amdgcn_sdot4(static_cast<int>(x[j][c].x), static_cast<int>(y[j][c].x), part[j], false);
+        part[j] = __builtin_amdgcn_sdot4(static_cast<int>(x[j][c].y), static_cast<int>(y[j][c].y), part[j], false);
+        part[j] = __builtin_amdgcn_sdot4(static_cast<int>(x[j][c].z), static_cast<int>(y[j][c].z), part[j], false);
+        part[j] = __builtin_amdgcn_sdot4(static_cast<int>(x[j][c].w), static_cast<int>(y[j][c].w), part[j], false);
       }
-    }
-    part += __builtin_amdgcn_update_dpp(0, part, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-    part += __builtin_amdgcn_update_dpp(0, part, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]: the entry's four lanes hold L
-    if (valid && part4 == 0) {
-      const float fv = static_cast<float>(shl_i32(H, a.lo_bits) + part) * __builtin_bit_cast(float, sbits);
-      if (fv >= thr[qid] * qscale[qid]) {
-        const uint32_t slot = atomicAdd(&a.cnt[qid], 1u);
-        if (slot < a.cap) a.cand[static_cast<uint64_t>(qid) * a.cap + slot] = Cand{fv * qinv[qid], row};
-        else a.overflow[qid] = 1u;
+      part[j] += __builtin_amdgcn_update_dpp(0, part[j], 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+      part[j] += __builtin_amdgcn_update_dpp(0, part[j], 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]: the entry's four lanes hold L
+      if (valid[j] && part4 == 0) {
+        const float fv = static_cast<float>(shl_i32(H[j], a.lo_bits) + part[j]) * __builtin_bit_cast(float, sbits[j]);
+        if (fv >= thr[qid[j]] * qscale[qid[j]]) {
+          const uint32_t slot = atomicAdd(&a.cnt[qid[j]], 1u);
+          if (slot < a.cap) a.cand[static_cast<uint64_t>(qid[j]) * a.cap + slot] = Cand{fv * qinv[qid[j]], row[j]};
+          else a.overflow[qid[j]] = 1u;
+        }
       }
     }
   }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // int8 two-stage build, software-pipelined (batches > 128: NB = 2 query blocks per wave, 64-row tiles).
