@@ -18,7 +18,7 @@ def _env():
 
 
 def test_bench_spawns_its_own_ranks():
-    for n in (2, 3):
+    for n in (2, 3, 8):                                # 8: what the driver's scaling run starts (N = 1, 2, 4, 8)
         r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--dry-launch"], capture_output=True, text=True, env=_env(), timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         out = json.loads(r.stdout.strip().splitlines()[-1])
