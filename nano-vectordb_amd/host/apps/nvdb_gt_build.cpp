@@ -15,7 +15,10 @@
 
 #include "nvdb/flat_index.h"
 #include "nvdb/flat_index_hip.h"
-#include "nvdb/flat_index_threads.h"
+#include "nvdb/flat_index_async.h"
+#include "nvdb/flat_index_omp.h"
+#include "nvdb/flat_index_pool.h"
+#include "nvdb/score_dispatch.h"
 #include "nvdb/gtbin_format.h"
 #include "nvdb_hip.h"
 

@@ -4,26 +4,14 @@
 
 #include <stdexcept>
 
-#include "nvdb/simd_dot.h"
+#include "nvdb/flat_index_omp.h"
+#include "nvdb/score_dispatch.h"
 
 #if defined(_OPENMP)
 #include <omp.h>
 #endif
 
 namespace nvdb {
-
-void ensure_supported_base_dtype(const VectorDataset& base) {
-  if (bytes_per_elem(base.dtype()) == 0) throw std::runtime_error("Unsupported base dtype (Float32/Float16/Int8 only)");
-}
-
-float score_query_base_at(const VectorDataset& base, const float* q, uint64_t row, uint32_t dim, uint32_t dt) {
-  switch (dt) {
-    case 1: return dot_f32(q, base.vector_ptr_f32(row), dim);
-    case 2: return dot_f32_f16base(q, base.vector_ptr_f16(row), dim);
-    case 3: return dot_f32_i8base(q, base.vector_ptr_i8(row), dim, *base.scale_ptr_i8(row));
-    default: throw std::runtime_error("Unsupported base dtype in score_query_base_at");
-  }
-}
 
 namespace {
 void scan_range(const VectorDataset& base, const float* q, uint64_t lo, uint64_t hi, TopKBuffer& out) {

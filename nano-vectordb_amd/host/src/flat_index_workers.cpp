@@ -1,12 +1,12 @@
 // FlatIndexAsync / FlatIndexPool: contiguous row blocks per worker, per-worker best-k lists, serial merge in
 // worker order.  Behaviour of reference src/flat_index_async.cpp:23-55 and src/flat_index_pool.cpp:98-215
 // (errors: "Empty base", "Null query", k == 0 -> empty; unsupported dtype checked once on the caller's thread).
-#include "nvdb/flat_index_threads.h"
-
 #include <algorithm>
 #include <stdexcept>
 
-#include "nvdb/flat_index.h"
+#include "nvdb/flat_index_async.h"
+#include "nvdb/flat_index_pool.h"
+#include "nvdb/score_dispatch.h"
 
 #if defined(__linux__)
 #include <pthread.h>
