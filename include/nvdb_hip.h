@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NVDB_HIP_ABI_VERSION 2
+#define NVDB_HIP_ABI_VERSION 3
 
 /* dtype codes == VecbinHeader::dtype (include/nvdb/vecbin_format.h:10-14) */
 enum { NVDB_DTYPE_F32 = 1, NVDB_DTYPE_F16 = 2, NVDB_DTYPE_I8 = 3 };
@@ -151,7 +151,8 @@ nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* ctx, nvdb_hip_scan_stats* stats)
 nvdb_status nvdb_hip_get_stats(nvdb_hip_ctx* ctx, nvdb_hip_scan_stats* stats);
 
 /* Merge per-shard top-k lists (e.g. after an RCCL all-gather): in[s][nq][k] -> out[nq][k] with
- * the same (score desc, id asc) order.  Device buffers, enqueued on hip_stream. */
+ * the same (score desc, id asc) order.  Device buffers, enqueued on hip_stream.  nshards*k <= 4096 (the lists of one
+ * query are ranked in LDS); beyond that NVDB_ERR_UNSUPPORTED -- use nvdb_merge_topk_host (the device group does). */
 nvdb_status nvdb_hip_merge_topk_dev(nvdb_hip_ctx* ctx, const uint64_t* dev_ids, const float* dev_scores,
                                     uint32_t nshards, uint32_t nq, uint32_t k, uint64_t* dev_out_ids,
                                     float* dev_out_scores, void* hip_stream);
@@ -164,6 +165,46 @@ nvdb_status nvdb_hip_merge_topk_strided_dev(nvdb_hip_ctx* ctx, const uint64_t* d
 /* Host version of the same merge (no GPU needed). */
 nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint32_t nshards, uint32_t nq,
                                  uint32_t k, uint64_t* out_ids, float* out_scores);
+
+/* ---------------------------------------------------------------------------------------------
+ * device group: ONE process driving several GPUs of a node (the reference has no multi-GPU path; the north star's
+ * "corpus row-sharded across the GPUs, RCCL all-gather of per-shard partial top-k over xGMI").  Shard g holds the
+ * contiguous rows [g*n/G, (g+1)*n/G) on devices[g] with global ids.  A batch is searched on every shard
+ * (nvdb_hip_search_batch_dev, one host thread per device for the enqueue), each device's [ids | scores] block
+ * (nq*k*12 bytes) is all-gathered with ONE ncclAllGather per device inside ncclGroupStart/End on the devices' streams,
+ * and the k-way merge runs on devices[0] (same (score desc, id asc) order: the result equals the unsharded search bit
+ * for bit).  RCCL is bound with dlopen at group creation; when it cannot serve the list (a device named twice, RCCL
+ * absent, NVDB_GROUP_NO_RCCL=1) the exchange is G peer copies into devices[0] and the same merge kernel.
+ * A shard whose self-check trips (list overflow, non-finite query) sends the sub-batch through the per-shard host API
+ * (which retries / falls back by itself) and a host-side merge; so does nshards*k > 4096 (merge kernel's LDS).
+ * One process per GPU (bench.py, torch.distributed) uses nvdb_hip_search_batch_dev + the caller's all-gather +
+ * nvdb_hip_merge_topk_strided_dev instead -- same kernels, same packed layout.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nvdb_hip_group nvdb_hip_group;
+typedef struct nvdb_hip_group_stats {
+  uint32_t shards;                /* G */
+  uint32_t exchange;              /* 1 = RCCL all-gather, 0 = peer copies into devices[0] */
+  uint32_t host_merge_fallbacks;  /* sub-batches of the last call that went through the host merge */
+  uint64_t bytes_per_rank;        /* packed block one rank contributes per sub-batch: nq*k*12 */
+} nvdb_hip_group_stats;
+
+nvdb_status nvdb_hip_group_create(const int* devices, uint32_t n_devices, nvdb_hip_group** out_group);
+void nvdb_hip_group_destroy(nvdb_hip_group* group);
+const char* nvdb_hip_group_last_error(const nvdb_hip_group* group);          /* NULL: last create() error */
+uint32_t nvdb_hip_group_size(const nvdb_hip_group* group);
+/* the shard's own context (options, statistics, corpus_info); owned by the group */
+nvdb_hip_ctx* nvdb_hip_group_ctx(nvdb_hip_group* group, uint32_t shard);
+/* 1 = RCCL, 0 = peer copies; *why (optional) names the reason */
+int nvdb_hip_group_exchange(const nvdb_hip_group* group, const char** why);
+/* row-shard a host corpus / the synthetic corpus over the group's devices (same arguments as the per-device calls) */
+nvdb_status nvdb_hip_group_upload_corpus(nvdb_hip_group* group, const void* rows, const float* scales, uint64_t n,
+                                         uint32_t dim, uint32_t dtype);
+nvdb_status nvdb_hip_group_generate_corpus(nvdb_hip_group* group, uint64_t seed, uint64_t n, uint32_t dim, uint32_t dtype);
+nvdb_status nvdb_hip_group_set_option(nvdb_hip_group* group, const char* key, int64_t value);   /* every shard */
+/* Same contract as nvdb_hip_search_batch (host queries in, [nq][k] global ids + scores out, any nq, k clamped). */
+nvdb_status nvdb_hip_group_search_batch(nvdb_hip_group* group, const float* queries, uint32_t nq, uint32_t k,
+                                        uint64_t* out_ids, float* out_scores, uint32_t* out_k_eff,
+                                        nvdb_hip_group_stats* stats);
 
 /* Tunables (defaults are what bench.py measures; the table with meanings is in INTEGRATION.md section 4b):
  * "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "chunk_growth", "cand_cap", "min_filter_batch", "mfma_boot",

@@ -10,6 +10,7 @@
 #include "nvdb/vector_dataset.h"
 
 struct nvdb_hip_ctx;
+struct nvdb_hip_group;
 
 namespace nvdb {
 
@@ -34,10 +35,12 @@ class FlatIndexHIP {
   mutable double last_kernel_ms_ = 0.0;
 };
 
-// Row-sharded flat index over several GPUs of one node (the reference has no multi-GPU path): shard g holds the
-// contiguous rows [g*N/G, (g+1)*N/G) on devices[g] with global ids; a batch is searched on all shards concurrently
-// (one host thread per GPU) and the per-shard top-k lists are merged on the host in the canonical order, which makes
-// the result identical to the single-GPU result.  (bench.py does the same across processes with an RCCL all-gather.)
+// Row-sharded flat index over several GPUs of one node, driven from ONE process (the reference has no multi-GPU path):
+// shard g holds the contiguous rows [g*N/G, (g+1)*N/G) on devices[g] with global ids.  Thin C++ over the device group of
+// the C ABI (nvdb_hip_group_*, include/nvdb_hip.h): per batch every shard is searched on its own stream, the per-shard
+// top-k blocks are exchanged by an RCCL all-gather over xGMI (peer copies when a device is listed twice), and the k-way
+// merge runs on devices[0] in the canonical order -- the result equals the single-GPU result bit for bit.
+// (bench.py does the same across one process per GPU with torch.distributed's all-gather.)
 class FlatIndexHIPSharded {
  public:
   FlatIndexHIPSharded(const VectorDataset* base, const std::vector<int>& devices);
@@ -47,12 +50,16 @@ class FlatIndexHIPSharded {
 
   std::vector<SearchResult> search_topk_dot(const float* q, uint32_t k) const { return search_topk_dot_batch(q, 1, k); }
   std::vector<SearchResult> search_topk_dot_batch(const float* queries, uint32_t nq, uint32_t k) const;
-  size_t shards() const { return ctx_.size(); }
+  size_t shards() const;
+  bool exchange_is_rccl() const;                       // false: peer copies (why: exchange_note())
+  const char* exchange_note() const;
+  unsigned host_merge_fallbacks() const { return fallbacks_; }   // sub-batches that went through the host merge so far
 
  private:
-  std::vector<nvdb_hip_ctx*> ctx_;
+  nvdb_hip_group* grp_ = nullptr;
   uint64_t n_ = 0;
   uint32_t dim_ = 0;
+  mutable unsigned fallbacks_ = 0;
 };
 
 }  // namespace nvdb

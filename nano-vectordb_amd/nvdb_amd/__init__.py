@@ -28,6 +28,9 @@ EXPORTS = [
     "nvdb_hip_get_stats", "nvdb_hip_collect_kernel_times", "nvdb_hip_merge_topk_dev", "nvdb_hip_merge_topk_strided_dev", "nvdb_merge_topk_host", "nvdb_hip_set_option",
     "nvdb_hip_refine_l2_topk", "nvdb_hip_refine_l2_topk_dev", "nvdb_synth_rows_f32", "nvdb_f32_to_f16",
     "nvdb_quantize_i8_rows",
+    "nvdb_hip_group_create", "nvdb_hip_group_destroy", "nvdb_hip_group_last_error", "nvdb_hip_group_size", "nvdb_hip_group_ctx",
+    "nvdb_hip_group_exchange", "nvdb_hip_group_upload_corpus", "nvdb_hip_group_generate_corpus", "nvdb_hip_group_set_option",
+    "nvdb_hip_group_search_batch",
 ]
 # only in libnvdb_hip_dev.so; the product library must NOT export them (tests/test_cabi_cpu.py)
 DEV_EXPORTS = ["nvdb_hip_debug_filter_variant", "nvdb_hip_debug_clock", "nvdb_hip_debug_clock_i8", "nvdb_permuted_tile", "nvdb_hip_debug_tile_ranges"]
@@ -58,6 +61,13 @@ class ScanStats(C.Structure):
         return {f: getattr(self, f) for f, _ in self._fields_}
 
 
+class GroupStats(C.Structure):
+    _fields_ = [("shards", C.c_uint32), ("exchange", C.c_uint32), ("host_merge_fallbacks", C.c_uint32), ("bytes_per_rank", C.c_uint64)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
 _lib = None
 _dev_lib = None
 
@@ -73,6 +83,18 @@ def _share_hip_runtime_with_torch():
     if spec is None or not spec.submodule_search_locations:
         return
     cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def _share_rccl_with_torch():
+    """Same for RCCL, which the device group binds with dlopen("librccl.so.1") on first use: PyTorch's bundled copy is
+    built against PyTorch's HIP runtime, so it is the one to have in the process (loaded lazily: only DeviceGroup needs it)."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
     if os.path.exists(cand):
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
@@ -109,6 +131,21 @@ def _bind(L, dev):
     L.nvdb_f32_to_f16.restype = None
     L.nvdb_quantize_i8_rows.argtypes = [vp, u64, u32, vp, vp]
     L.nvdb_quantize_i8_rows.restype = None
+    L.nvdb_hip_group_create.argtypes = [C.POINTER(C.c_int), u32, C.POINTER(vp)]
+    L.nvdb_hip_group_destroy.argtypes = [vp]
+    L.nvdb_hip_group_destroy.restype = None
+    L.nvdb_hip_group_last_error.argtypes = [vp]
+    L.nvdb_hip_group_last_error.restype = C.c_char_p
+    L.nvdb_hip_group_size.argtypes = [vp]
+    L.nvdb_hip_group_size.restype = u32
+    L.nvdb_hip_group_ctx.argtypes = [vp, u32]
+    L.nvdb_hip_group_ctx.restype = vp
+    L.nvdb_hip_group_exchange.argtypes = [vp, C.POINTER(C.c_char_p)]
+    L.nvdb_hip_group_exchange.restype = C.c_int
+    L.nvdb_hip_group_upload_corpus.argtypes = [vp, vp, vp, u64, u32, u32]
+    L.nvdb_hip_group_generate_corpus.argtypes = [vp, u64, u64, u32, u32]
+    L.nvdb_hip_group_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.nvdb_hip_group_search_batch.argtypes = [vp, vp, u32, u32, vp, vp, C.POINTER(u32), C.POINTER(GroupStats)]
     for name in EXPORTS:
         getattr(L, name)
     if dev:
@@ -311,6 +348,81 @@ class HipContext:
 
     def refine_l2_topk_dev(self, dev_q, dev_cand, Q, R, K, dev_out_ids, dev_out_dist, stream=None):
         self._chk(self.lib.nvdb_hip_refine_l2_topk_dev(self.h, dev_q, dev_cand, Q, R, K, dev_out_ids, dev_out_dist, stream))
+
+
+class DeviceGroup:
+    """One process, several GPUs (nvdb_hip_group): corpus row-sharded over `devices`, per-shard top-k exchanged by an RCCL
+    all-gather (or peer copies when a device is listed twice), merged on devices[0]."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        _share_rccl_with_torch()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        st = self.lib.nvdb_hip_group_create(arr, len(devices), C.byref(h))
+        if st:
+            raise NvdbError(st, self.lib.nvdb_hip_group_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nvdb_hip_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st):
+        if st:
+            raise NvdbError(st, self.lib.nvdb_hip_group_last_error(self.h).decode())
+
+    def size(self):
+        return self.lib.nvdb_hip_group_size(self.h)
+
+    def exchange(self):
+        why = C.c_char_p()
+        mode = self.lib.nvdb_hip_group_exchange(self.h, C.byref(why))
+        return ("rccl" if mode == 1 else "peer-copy"), (why.value or b"").decode()
+
+    def shard_stats(self, shard):
+        s = ScanStats()
+        st = self.lib.nvdb_hip_get_stats(self.lib.nvdb_hip_group_ctx(self.h, shard), C.byref(s))
+        if st:
+            raise NvdbError(st, "get_stats")
+        return s.as_dict()
+
+    def upload_corpus(self, rows, dtype, scales=None):
+        if dtype == DT_F16 and getattr(rows, "dtype", None) == np.float16:
+            rows = rows.view(np.uint16)
+        rows = np.ascontiguousarray(rows, dtype=_NP_OF[dtype])
+        sc = np.ascontiguousarray(scales, dtype=np.float32) if scales is not None else None
+        self._chk(self.lib.nvdb_hip_group_upload_corpus(self.h, rows.ctypes.data, sc.ctypes.data if sc is not None else None,
+                                                        rows.shape[0], rows.shape[1], dtype))
+
+    def generate_corpus(self, seed, n, dim, dtype):
+        self._chk(self.lib.nvdb_hip_group_generate_corpus(self.h, seed, n, dim, dtype))
+
+    def set_option(self, key, value):
+        self._chk(self.lib.nvdb_hip_group_set_option(self.h, key.encode(), int(value)))
+
+    def search_batch(self, queries, k, want_stats=False):
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        if queries.ndim == 1:
+            queries = queries[None, :]
+        nq = queries.shape[0]
+        ids = np.full((nq, max(k, 1)), np.iinfo(np.uint64).max, dtype=np.uint64)
+        scores = np.full((nq, max(k, 1)), -np.inf, dtype=np.float32)
+        keff = C.c_uint32(0)
+        gs = GroupStats()
+        self._chk(self.lib.nvdb_hip_group_search_batch(self.h, queries.ctypes.data, nq, k, ids.ctypes.data, scores.ctypes.data,
+                                                       C.byref(keff), C.byref(gs)))
+        ke = keff.value if k > 0 else 0
+        if want_stats:
+            return ids[:, :ke], scores[:, :ke], gs.as_dict()
+        return ids[:, :ke], scores[:, :ke]
 
 
 class FlatIndexHIP:

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in nvdb_hip.h but not exported"
     assert declared == set(nvdb_amd.EXPORTS), declared ^ set(nvdb_amd.EXPORTS)
-    assert lib.nvdb_hip_abi_version() == 2
+    assert lib.nvdb_hip_abi_version() == 3
 
 
 def test_product_library_carries_only_the_drop_in_surface(lib):
@@ -64,6 +64,24 @@ def test_fails_loudly_without_gpu(lib):
     with pytest.raises(nvdb_amd.NvdbError) as e:
         nvdb_amd.HipContext(0)
     assert e.value.status == 2 and "HIP" in str(e.value)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_device_group_fails_loudly_without_gpu(lib):
+    """The multi-GPU group has no CPU fallback either, and creating one must not need RCCL to be loadable."""
+    with pytest.raises(nvdb_amd.NvdbError) as e:
+        nvdb_amd.DeviceGroup([0, 1])
+    assert e.value.status == 2 and "HIP" in str(e.value)
+    import ctypes
+    assert lib.nvdb_hip_group_create(None, 0, ctypes.byref(ctypes.c_void_p())) == 1          # empty device list: INVALID
+    assert lib.nvdb_hip_group_size(None) == 0 and lib.nvdb_hip_group_exchange(None, None) == -1
+
+
+def test_product_library_does_not_link_rccl(lib):
+    """RCCL is bound with dlopen when a group is created; single-GPU users of libnvdb_hip.so never load it."""
+    import subprocess
+    needed = subprocess.run(["objdump", "-p", nvdb_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "librccl" not in needed and "libamdhip64" in needed
 
 
 def test_host_f16_conversion_matches_oracle(lib, oracle):
