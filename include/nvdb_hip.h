@@ -39,7 +39,8 @@ typedef enum nvdb_status {
 } nvdb_status;
 
 /* The flat path takes ANY k (clamped to the row count like the reference, src/flat_index.cpp:24): k <= 64 runs on
- * wavefront-resident lists / the MFMA filter, larger k on the any-k path (scores -> radix select -> sort).
+ * wavefront-resident lists / the MFMA filter, 65..1024 on the filter path where it is eligible (MFMA bootstrap, a dtype / dim
+ * with a bootstrap build, >= 512*k rows), every other k > 64 on the any-k path (scores -> radix select -> sort).
  * Largest K of the refine path = the reference's NVDB_CUDA_KMAX = 64 (src/cuda_refine.cu:12-14, 858-862). */
 #define NVDB_HIP_REFINE_KMAX 64
 
@@ -62,7 +63,7 @@ typedef struct nvdb_hip_timing {
 
 /* What the last flat search did (for tests, bench.py and the roofline arithmetic). */
 typedef struct nvdb_hip_scan_stats {
-  uint32_t path;               /* 1 = exact fp32 scan, 2 = MFMA filter + exact rescore, 3 = any-k (k > 64) */
+  uint32_t path;               /* 1 = exact fp32 scan, 2 = MFMA filter + exact rescore (k <= 1024), 3 = any-k (k > 64 off the filter path) */
   uint32_t chunks;             /* corpus chunks (kernel launches of the dominant kernel)          */
   uint64_t rows_scanned;       /* rows x query-tiles streamed by the dominant kernel              */
   uint64_t candidates;         /* (query,row) pairs that reached the exact rescore                */

@@ -342,9 +342,11 @@ __global__ __launch_bounds__(256) void select_kernel(
   // survive later searches until nvdb_hip_search_check reads and clears them -- a caller that enqueues many searches
   // and checks once still learns about a failure in any of them.  (any_overflow[-6], [-5] = misc[0], misc[1]: bound
   // violations and wave-log overflow, final here because every earlier kernel of this search has completed.)
-  if (mode == 1 && tid == 0) {
-    if (overflow[q]) { atomicOr(any_overflow, 1u); atomicOr(any_overflow + 6, 1u); }
-    if (q == 0) {
+  // mode 3 = mode 1 without the sticky fold: the host API judges its own search by misc[0], [1], [6] alone and must
+  // neither set nor clear what device-API searches left for the next nvdb_hip_search_check.
+  if ((mode & 1) && tid == 0) {
+    if (overflow[q]) { atomicOr(any_overflow, 1u); if (mode == 1) atomicOr(any_overflow + 6, 1u); }
+    if (mode == 1 && q == 0) {
       const uint32_t viol = any_overflow[-6], logovf = any_overflow[-5];
       if (viol) atomicAdd(any_overflow + 7, viol);
       if (logovf) atomicOr(any_overflow + 8, 1u);
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void select_kernel(
       }
     }
     __syncthreads();
-    if (mode == 1) {
+    if (mode & 1) {
       const uint32_t c = m < k ? m : k;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256) void select_kernel(
       __syncthreads();
     }
   }
-  if (mode == 1) {
+  if (mode & 1) {
     const uint32_t c = m < k ? m : k;
     for (uint32_t j = tid; j < out_k; j += nth) {
       const bool have = j < c;

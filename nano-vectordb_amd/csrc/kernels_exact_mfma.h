@@ -1,0 +1,336 @@
+// kernels_exact_mfma.h -- the reference's fp32 score arithmetic on the fp32 matrix cores.
+//
+// The reference's AVX2 kernels (src/simd_dot.cpp:26-49, 102-124, 160-199) keep EIGHT fp32 accumulators: lane j of the
+// 8-wide register sums q[8i+j] * x[8i+j] over i = 0, 1, 2, ... with one fused multiply-add per step, and the result is
+// ((a0+a4)+(a1+a5))+((a2+a6)+(a3+a7)).  `v_mfma_f32_16x16x4_f32` computes D = A(16x4) * B(4x16) + C with the four
+// products of a K-step folded into C one after the other by fused multiply-adds (MI355X_MICROARCH.md: "exact f32
+// (== fmaf chain, bitwise)"), so ONE accumulator tile per reference lane j reproduces that lane's chain bit for bit when its
+// K operands are the elements 8(4t+k)+j, k = 0..3, of step t:
+//
+//     acc_j[row m][query n]  =  fma chain over i = 0 .. dim/8-1 of  q_n[8i+j] * x_m[8i+j]        (i = 4t + k)
+//
+// 8 accumulator tiles (32 registers), 8 MFMAs per 32 elements of K, then the reference's reduction tree on the VALU.
+// Rate: 64 flop / clk / SIMD = 157 TFLOP/s peak, against ~29 TFLOP/s of the VALU kernels of kernels_exact.h
+// (scan_exact_kernel / scores_exact_kernel), which stay for every shape this file does not take.
+//
+// Mapping (one wave = 16 queries x 16-row tiles):
+//   * B operand = queries, STATIONARY in registers: lane (n = lane % 16, kq = lane / 16) keeps q_n[8(4t+kq) + j] for all
+//     t < DIM/32, j < 8: DIM/4 registers (192 at d = 768; hence DIM <= 768 and one wave per SIMD).
+//   * A operand = corpus rows, streamed straight from global memory into registers: lane (m = lane % 16, kq) loads the 8
+//     consecutive elements [8(4t+kq), +8) of row m -- one 16-byte load for fp16 rows, 8 bytes for int8, 32 for fp32 --
+//     converts them to 8 floats (exact conversions, like vcvtph2ps / vpmovsxbd+vcvtdq2ps) and feeds element j to chain j.
+//     The load of the NEXT tile's step t is issued into the same registers right after step t's bytes are converted: one
+//     whole tile (6144 MFMA cycles) of prefetch distance without a second register set (fp32 rows: half a tile).
+//   * D: lane holds rows 4 * (lane / 16) + v, v = 0..3, of query lane % 16.
+//   * workgroup = 4 waves = up to 4 blocks of 16 queries over the SAME rows (HBM sees a row once; the other waves hit
+//     L2), or -- for fewer queries -- the waves split the workgroup's tiles.
+//   * top-k (scan kernel): per query a best-first list of <= 64 entries in LDS, entry e handled by lane e; the k-th best
+//     (score, row) of the lane's own query sits in two registers, so the common case "nothing in this tile beats it" is
+//     four compares per lane and one ballot per wave.  Order: (score desc, id asc), as everywhere.
+// Shapes taken: DIM in {128, 256, 384, 512, 768} with dim % 32 == 0 (no scalar tail; the tails' special orders stay with
+// the VALU kernels), all three dtypes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_exact.h"
+
+namespace nvdbhip {
+
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+template <int DT> struct ExactRaw;                       // raw bytes of one K-step of one lane (8 elements)
+template <> struct ExactRaw<DT_F16> { uint4 v; };
+template <> struct ExactRaw<DT_I8> { uint2 v; };
+template <> struct ExactRaw<DT_F32> { float4 a, b; };
+
+template <int DT>
+__device__ __forceinline__ ExactRaw<DT> exact_raw_load(const char* p) {
+  ExactRaw<DT> r;
+  if constexpr (DT == DT_F16) r.v = *reinterpret_cast<const uint4*>(p);
+  else if constexpr (DT == DT_I8) r.v = *reinterpret_cast<const uint2*>(p);
+  else { r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 16); }
+  return r;
+}
+template <int DT>
+__device__ __forceinline__ void exact_raw_to_f32(const ExactRaw<DT>& r, float (&x)[8]) {
+  if constexpr (DT == DT_F16) {
+    x[0] = half_bits_to_float(r.v.x & 0xFFFFu); x[1] = half_bits_to_float(r.v.x >> 16);
+    x[2] = half_bits_to_float(r.v.y & 0xFFFFu); x[3] = half_bits_to_float(r.v.y >> 16);
+    x[4] = half_bits_to_float(r.v.z & 0xFFFFu); x[5] = half_bits_to_float(r.v.z >> 16);
+    x[6] = half_bits_to_float(r.v.w & 0xFFFFu); x[7] = half_bits_to_float(r.v.w >> 16);
+  } else if constexpr (DT == DT_I8) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = static_cast<float>(static_cast<int>(r.v.x << (24 - 8 * j)) >> 24);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[4 + j] = static_cast<float>(static_cast<int>(r.v.y << (24 - 8 * j)) >> 24);
+  } else {
+    x[0] = r.a.x; x[1] = r.a.y; x[2] = r.a.z; x[3] = r.a.w; x[4] = r.b.x; x[5] = r.b.y; x[6] = r.b.z; x[7] = r.b.w;
+  }
+}
+
+template <int DT> constexpr int exact_bpe() { return DT == DT_F32 ? 4 : (DT == DT_F16 ? 2 : 1); }
+// K-steps of prefetch distance: a whole tile, half a tile for fp32 rows (8 registers per step instead of 4 / 2)
+template <int DT, int DIM> constexpr int exact_ring() { return DT == DT_F32 ? DIM / 64 : DIM / 32; }
+
+// The stationary operand: this lane's share of query `qi` (zeros for a padding query).
+template <int DIM>
+__device__ __forceinline__ void exact_load_bq(const float* __restrict__ q32, uint32_t qi, uint32_t nq, int kq, float (&bq)[DIM / 32][8]) {
+#pragma unroll
+  for (int t = 0; t < DIM / 32; ++t) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (qi < nq) {
+      const float* p = q32 + static_cast<uint64_t>(qi) * DIM + 8 * (4 * t + kq);
+      a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    bq[t][0] = a.x; bq[t][1] = a.y; bq[t][2] = a.z; bq[t][3] = a.w; bq[t][4] = b.x; bq[t][5] = b.y; bq[t][6] = b.z; bq[t][7] = b.w;
+  }
+}
+
+// One 16-row tile against the wave's 16 queries.  `raw` holds this tile's K-steps (ring of RING steps, the rest is fetched as
+// the loop goes); while they are consumed the same registers receive the steps of the tile at `next` (lane's row pointer
+// + its kq offset; pass the current pointer again for the last tile: the bytes are loaded and never used).
+// Returns s[v] = reference score of (row 4 * (lane / 16) + v of the tile, query lane % 16), int8: before the row scale.
+template <int DT, int DIM>
+__device__ __forceinline__ void exact_tile(const char* cur, const char* next, ExactRaw<DT> (&raw)[exact_ring<DT, DIM>()],
+                                           const float (&bq)[DIM / 32][8], float (&s)[4]) {
+  constexpr int T = DIM / 32, RING = exact_ring<DT, DIM>(), STEP_BYTES = 32 * exact_bpe<DT>();
+  floatx4_t acc[8];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float x[8];
+    exact_raw_to_f32<DT>(raw[t % RING], x);
+    // refill the slot: step t + RING of this tile, or step t + RING - T of the next one
+    if (t + RING < T) raw[t % RING] = exact_raw_load<DT>(cur + (t + RING) * STEP_BYTES);
+    else raw[t % RING] = exact_raw_load<DT>(next + (t + RING - T) * STEP_BYTES);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (t == 0) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], bq[0][j], floatx4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      else acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], bq[t][j], acc[j], 0, 0, 0);
+    }
+    // keep step t's refill load inside step t: left alone, the scheduler gathers all of a tile's loads behind its last MFMA
+    // and the prefetch distance collapses to the epilogue
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    // (lo + hi), hadd, hadd  (simd_dot.cpp:38-44)
+    const float s0 = acc[0][v] + acc[4][v], s1 = acc[1][v] + acc[5][v], s2 = acc[2][v] + acc[6][v], s3 = acc[3][v] + acc[7][v];
+    s[v] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+constexpr uint32_t EXACT_MFMA_ROWS = 16;                 // rows per tile (MFMA M)
+constexpr uint32_t EXACT_MFMA_QB = 16;                   // queries per wave (MFMA N)
+
+// wave -> (query block, row slice) of a workgroup that serves `nqb` (1..4) blocks of 16 queries
+__device__ __forceinline__ void exact_wave_role(uint32_t nqb, uint32_t wave, uint32_t& qb, uint32_t& slice, uint32_t& nslice) {
+  const uint32_t QW = nqb >= 3 ? 4u : nqb;               // 1, 2 or 4 query blocks side by side
+  qb = wave % QW; slice = wave / QW; nslice = 4u / QW;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan: grid = (row splits P, ceil(nq / 64)), block = 256.  Same contract as scan_exact_kernel: every wave appends the <= k
+// best rows of its tiles (those that also clear the query's global threshold) to its queries' candidate lists; a query
+// receives at most P * nslice * k entries.
+// ------------------------------------------------------------------------------------------------
+template <int DT, int DIM>
+__global__ __launch_bounds__(256, 1) void scan_exact_mfma_kernel(
+    const void* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
+    const float* __restrict__ q32, uint32_t nq, uint32_t k, const float* __restrict__ thr,
+    Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t* __restrict__ overflow) {
+  static_assert(DIM % 32 == 0 && DIM <= 768, "whole MFMA K-steps; 16 queries x DIM fp32 in registers");
+  constexpr int BPE = exact_bpe<DT>(), RING = exact_ring<DT, DIM>(), STEP_BYTES = 32 * BPE;
+  constexpr uint64_t ROW_BYTES = static_cast<uint64_t>(DIM) * BPE;
+  __shared__ float l_s[4][EXACT_MFMA_QB][64];            // per wave and query: best-first list, entry e <-> lane e
+  __shared__ uint32_t l_id[4][EXACT_MFMA_QB][64];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n16 = lane & 15, kq = lane >> 4;
+  const uint32_t qg0 = blockIdx.y * 64u;
+  const uint32_t nqb_all = (nq - qg0 + EXACT_MFMA_QB - 1) / EXACT_MFMA_QB, nqb = nqb_all < 4u ? nqb_all : 4u;
+  uint32_t qb, slice, nslice;
+  exact_wave_role(nqb, wave, qb, slice, nslice);
+  if (qb >= nqb) return;                                  // three blocks on four waves: the fourth has no queries
+  const uint32_t qi = qg0 + qb * EXACT_MFMA_QB + n16;     // this lane's query
+
+  float bq[DIM / 32][8];
+  exact_load_bq<DIM>(q32, qi, nq, kq, bq);
+
+  // this workgroup's tiles, this wave's share of them
+  const uint32_t P = gridDim.x, p = blockIdx.x;
+  const uint32_t tiles = (row_hi - row_lo + EXACT_MFMA_ROWS - 1) / EXACT_MFMA_ROWS;
+  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * p / P), t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * (p + 1) / P);
+
+  // per lane: the k-th best (score, row) of ITS query so far -- what a new row must beat -- and the list length
+  float thr_s = NEG_INF;
+  uint32_t thr_id = 0xFFFFFFFFu, my_cnt = 0;
+  const float gthr = (thr != nullptr && qi < nq) ? thr[qi] : NEG_INF;
+  const bool real = qi < nq;
+
+  const char* gbase = static_cast<const char*>(rows);
+  auto lane_ptr = [&](uint32_t tile) -> const char* {     // row (tile, m = lane % 16), clamped into the range; + this lane's K offset
+    uint32_t r = row_lo + tile * EXACT_MFMA_ROWS + static_cast<uint32_t>(n16);
+    r = r < row_hi ? r : row_hi - 1;
+    return gbase + static_cast<uint64_t>(r) * ROW_BYTES + static_cast<uint32_t>(kq) * (8 * BPE);
+  };
+  uint32_t tile = t_lo + slice;
+  if (tile >= t_hi) return;
+  // int8: the row scales of this lane's four rows travel one tile ahead, issued BEFORE that tile's row loads -- a load issued
+  // behind them would have to wait for all of them (vmcnt counts in issue order) and drain the prefetch once per tile
+  float sc_cur[4] = {1.f, 1.f, 1.f, 1.f};
+  auto load_scales = [&](uint32_t tl, float (&dst)[4]) {
+    if constexpr (DT == DT_I8) {
+      const uint32_t r0 = row_lo + tl * EXACT_MFMA_ROWS + 4u * static_cast<uint32_t>(kq);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dst[v] = scales[r0 + v < row_hi ? r0 + v : row_hi - 1];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  load_scales(tile, sc_cur);
+  ExactRaw<DT> raw[RING];
+  const char* cur = lane_ptr(tile);
+#pragma unroll
+  for (int t = 0; t < RING; ++t) { raw[t] = exact_raw_load<DT>(cur + t * STEP_BYTES); __builtin_amdgcn_sched_barrier(0); }   // in step order, as the loop refills them: the counted vmcnt waits need one issue order on both paths into the loop
+
+  for (; tile < t_hi; tile += nslice) {
+    const uint32_t nxt = tile + nslice < t_hi ? tile + nslice : tile;
+    const char* next = lane_ptr(nxt);
+    float sc_nxt[4] = {1.f, 1.f, 1.f, 1.f};
+    load_scales(nxt, sc_nxt);
+    float s[4];
+    exact_tile<DT, DIM>(cur, next, raw, bq, s);
+    cur = next;
+    const uint32_t row0 = row_lo + tile * EXACT_MFMA_ROWS + 4u * static_cast<uint32_t>(kq);     // this lane's rows: row0 + v
+    if constexpr (DT == DT_I8) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { s[v] = s[v] * sc_cur[v]; sc_cur[v] = sc_nxt[v]; }                           // simd_dot.cpp:198
+    }
+    bool pass[4];
+    bool any = false;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const uint32_t row = row0 + v;
+      pass[v] = real && row < row_hi && s[v] >= gthr && (my_cnt < k || better(s[v], row, thr_s, thr_id));
+      any = any || pass[v];
+    }
+    if (!__ballot(any)) continue;
+    // rare: file the passing (row, query) pairs, one at a time, into the queries' lists
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      unsigned long long m = __ballot(pass[v]);
+      while (m) {
+        const int L = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t g = static_cast<uint32_t>(L) & 15u;                                  // the pair's query (block-relative)
+        const float cs = readlane_f(s[v], L);
+        const uint32_t cid = row_lo + tile * EXACT_MFMA_ROWS + 4u * (static_cast<uint32_t>(L) >> 4) + v;
+        const uint32_t c = readlane_u(my_cnt, static_cast<int>(g));                         // (lanes g, g + 16, .. hold query g's state)
+        const float ts = readlane_f(thr_s, static_cast<int>(g));
+        const uint32_t tid = readlane_u(thr_id, static_cast<int>(g));
+        if (!(c < k || better(cs, cid, ts, tid))) continue;                                  // an earlier pair of this tile raised the bar
+        float es = l_s[wave][g][lane];
+        uint32_t eid = l_id[wave][g][lane];
+        const bool ahead = static_cast<uint32_t>(lane) < c && better(es, eid, cs, cid);
+        const uint32_t pos = static_cast<uint32_t>(__builtin_popcountll(__ballot(ahead)));
+        const float up_s = __shfl_up(es, 1);
+        const uint32_t up_id = __shfl_up(eid, 1);
+        if (static_cast<uint32_t>(lane) > pos) { es = up_s; eid = up_id; }
+        else if (static_cast<uint32_t>(lane) == pos) { es = cs; eid = cid; }
+        const uint32_t c2 = c < k ? c + 1 : k;
+        if (static_cast<uint32_t>(lane) < c2) { l_s[wave][g][lane] = es; l_id[wave][g][lane] = eid; }
+        const float nts = readlane_f(es, static_cast<int>(k) - 1);
+        const uint32_t ntid = readlane_u(eid, static_cast<int>(k) - 1);
+        if (static_cast<uint32_t>(n16) == g) {
+          my_cnt = c2;
+          if (c2 == k) { thr_s = nts; thr_id = ntid; }
+        }
+      }
+    }
+  }
+  // append this wave's lists (global candidate lists; select_kernel orders them)
+  for (uint32_t g = 0; g < EXACT_MFMA_QB; ++g) {
+    const uint32_t q = qg0 + qb * EXACT_MFMA_QB + g;
+    const uint32_t c = readlane_u(my_cnt, static_cast<int>(g));
+    if (q >= nq || c == 0) continue;
+    uint32_t slot0 = 0;
+    if (lane == 0) slot0 = atomicAdd(&cnt[q], c);
+    slot0 = readlane_u(slot0, 0);
+    if (static_cast<uint32_t>(lane) < c) {
+      const uint32_t slot = slot0 + lane;
+      if (slot < cap) cand[static_cast<uint64_t>(q) * cap + slot] = Cand{l_s[wave][g][lane], l_id[wave][g][lane]};
+      else overflow[q] = 1u;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scores: out[q][row] for every (query, row) -- the any-k path's score matrix (kernels_largek.h).
+// grid = (row splits, ceil(nq / 64)), block = 256; ld = row stride of `out` (a multiple of 4: 16-byte stores of 4 rows).
+// ------------------------------------------------------------------------------------------------
+template <int DT, int DIM>
+__global__ __launch_bounds__(256, 1) void scores_exact_mfma_kernel(const void* __restrict__ rows, const float* __restrict__ scales, uint32_t n,
+                                                                   const float* __restrict__ q32, uint32_t nq, float* __restrict__ out, uint64_t ld) {
+  static_assert(DIM % 32 == 0 && DIM <= 768, "whole MFMA K-steps; 16 queries x DIM fp32 in registers");
+  constexpr int BPE = exact_bpe<DT>(), RING = exact_ring<DT, DIM>(), STEP_BYTES = 32 * BPE;
+  constexpr uint64_t ROW_BYTES = static_cast<uint64_t>(DIM) * BPE;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n16 = lane & 15, kq = lane >> 4;
+  const uint32_t qg0 = blockIdx.y * 64u;
+  const uint32_t nqb_all = (nq - qg0 + EXACT_MFMA_QB - 1) / EXACT_MFMA_QB, nqb = nqb_all < 4u ? nqb_all : 4u;
+  uint32_t qb, slice, nslice;
+  exact_wave_role(nqb, wave, qb, slice, nslice);
+  if (qb >= nqb) return;
+  const uint32_t qi = qg0 + qb * EXACT_MFMA_QB + n16;
+  float bq[DIM / 32][8];
+  exact_load_bq<DIM>(q32, qi, nq, kq, bq);
+  const uint32_t P = gridDim.x, p = blockIdx.x;
+  const uint32_t tiles = (n + EXACT_MFMA_ROWS - 1) / EXACT_MFMA_ROWS;
+  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * p / P), t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * (p + 1) / P);
+  const char* gbase = static_cast<const char*>(rows);
+  auto lane_ptr = [&](uint32_t tile) -> const char* {
+    uint32_t r = tile * EXACT_MFMA_ROWS + static_cast<uint32_t>(n16);
+    r = r < n ? r : n - 1;
+    return gbase + static_cast<uint64_t>(r) * ROW_BYTES + static_cast<uint32_t>(kq) * (8 * BPE);
+  };
+  uint32_t tile = t_lo + slice;
+  if (tile >= t_hi) return;
+  float sc_cur[4] = {1.f, 1.f, 1.f, 1.f};              // int8 row scales, one tile ahead (see scan_exact_mfma_kernel)
+  auto load_scales = [&](uint32_t tl, float (&dst)[4]) {
+    if constexpr (DT == DT_I8) {
+      const uint32_t r0 = tl * EXACT_MFMA_ROWS + 4u * static_cast<uint32_t>(kq);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dst[v] = scales[r0 + v < n ? r0 + v : n - 1];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  load_scales(tile, sc_cur);
+  ExactRaw<DT> raw[RING];
+  const char* cur = lane_ptr(tile);
+#pragma unroll
+  for (int t = 0; t < RING; ++t) { raw[t] = exact_raw_load<DT>(cur + t * STEP_BYTES); __builtin_amdgcn_sched_barrier(0); }
+  for (; tile < t_hi; tile += nslice) {
+    const uint32_t nxt = tile + nslice < t_hi ? tile + nslice : tile;
+    const char* next = lane_ptr(nxt);
+    float sc_nxt[4] = {1.f, 1.f, 1.f, 1.f};
+    load_scales(nxt, sc_nxt);
+    float s[4];
+    exact_tile<DT, DIM>(cur, next, raw, bq, s);
+    cur = next;
+    const uint32_t row0 = tile * EXACT_MFMA_ROWS + 4u * static_cast<uint32_t>(kq);
+    if constexpr (DT == DT_I8) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { s[v] = s[v] * sc_cur[v]; sc_cur[v] = sc_nxt[v]; }
+    }
+    if (qi < nq) {
+      float* o = out + static_cast<uint64_t>(qi) * ld + row0;
+      if (row0 + 3 < n) *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
+      else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) if (row0 + v < n) o[v] = s[v];
+      }
+    }
+  }
+}
+
+}  // namespace nvdbhip

@@ -1224,14 +1224,17 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   constexpr int KSTEPS = DIM / 32;
   constexpr int ROW_BYTES = DIM;
   constexpr int TROWS = FILTER_ROWS * MB;          // corpus rows per tile
-  constexpr int NSTAGE = MB == 2 ? 3 : FILTER_STAGES_I8;
+  constexpr int NSTAGE = (MB == 2 || DIM > 768) ? 3 : FILTER_STAGES_I8;
   constexpr int DATA_BYTES = TROWS * ROW_BYTES;
   constexpr int STAGE_BYTES = DATA_BYTES + 4 * 1024;
   constexpr int PIECES = DATA_BYTES / 1024;
   constexpr int PPW = PIECES / 4;
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
-  static_assert(DIM % 256 == 0 && DIM <= 768, "row stride multiple of 256 bytes; int32 range of 128*H + L");
-  static_assert(PIECES % 4 == 0 && (MB * KSTEPS) % PPW == 0 && 2 * KSTEPS <= 64 && KSTEPS % 2 == 0, "shape");
+  // dims up to 1536 (768 < DIM: NB = 1, MB = 1 -- 32 queries per wave, 192 AGPRs of hi-plane fragments, 32-row tiles in three
+  // 52 KB stages).  int32 range of (H << 7) + L at any dim: prep_q8_kernel keeps the L1 norm of a query's hi plane below
+  // I8_HI_L1_MAX, so |H| < 2^23 whatever the dim.
+  static_assert(DIM % 256 == 0 && DIM <= 1536 && (DIM <= 768 || (NB == 1 && MB == 1)), "row stride multiple of 256 bytes; fragments of one wave <= 192 registers");
+  static_assert(PIECES % 4 == 0 && (MB * KSTEPS) % PPW == 0 && NB * KSTEPS <= 64 && KSTEPS % 2 == 0, "shape");
   static_assert(NB == 1 || NB == 2, "one or two 32-query blocks per wave");
   static_assert((MB == 1 || MB == 2) && NSTAGE * STAGE_BYTES <= 160 * 1024 && (NSTAGE - 2) * (PPW + 1) < 64, "LDS / vmcnt range");
 
@@ -2192,7 +2195,9 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const void* __restric
     if constexpr (DT == DT_I8) {
       const float sc = scales[r];
       nrm *= fabsf(sc);
-      if (!(sc >= 0.f) && lane == 0) out_bits[1] = 1u;      // a negative (or NaN) row scale: the biased-accumulator test assumes none
+      // a negative / NaN row scale, or one so large that 2^23 * scale overflows (inf - inf = NaN would lose the flag silently):
+      // the biased-accumulator test assumes neither -> such corpora take the in-loop (unbiased) build
+      if (!(sc >= 0.f && sc < 1e30f) && lane == 0) out_bits[1] = 1u;
     }
     wmax = fmaxf(wmax, nrm);
   }

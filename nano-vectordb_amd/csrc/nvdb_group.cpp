@@ -269,13 +269,13 @@ void nvdb_hip_group_destroy(nvdb_hip_group* g) {
   if (!g) return;
   for (size_t i = 0; i < g->stream.size(); ++i) { (void)hipSetDevice(g->devices[i]); (void)hipStreamSynchronize(g->stream[i]); }
   for (ncclComm_t c : g->comm) if (c) (void)rccl().CommDestroy(c);
-  for (size_t i = 0; i < g->devices.size(); ++i) {
+  for (size_t i = 0; i < g->ctx.size(); ++i) {       // only devices a context was created on (a bad ordinal never reaches HIP)
     (void)hipSetDevice(g->devices[i]);
     for (auto* v : {&g->dq, &g->packed, &g->gathered}) if (i < v->size() && (*v)[i]) (void)hipFree((*v)[i]);
     if (i < g->done.size()) (void)hipEventDestroy(g->done[i]);
     if (i < g->stream.size()) (void)hipStreamDestroy(g->stream[i]);
   }
-  if (g->merged) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->merged); }
+  if (g->merged && !g->ctx.empty()) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->merged); }
   if (g->pinned) (void)hipHostFree(g->pinned);
   for (nvdb_hip_ctx* c : g->ctx) nvdb_hip_destroy(c);
   delete g;

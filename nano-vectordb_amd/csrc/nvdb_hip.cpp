@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "kernels_exact.h"
+#include "kernels_exact_mfma.h"
 #include "kernels_filter.h"
 #include "kernels_largek.h"
 #include "kernels_refine.h"
@@ -83,6 +84,7 @@ struct nvdb_hip_ctx {
   hipEvent_t launch_e0 = nullptr, launch_e1 = nullptr;   // attached to the next filter launch (hipExtLaunchKernelGGL): its own start/stop timestamps, no extra packets
   std::vector<hipEvent_t> kl_pool;                  // recycled events of collected launches
   uint32_t prog_slot = 0;                          // next free region of the rendezvous counters (reset per search)
+  int64_t opt_exact_mfma = 1;                      // exact fp32-order scores on the fp32 matrix cores where the shape allows (kernels_exact_mfma.h); 0: VALU kernels only
   int64_t opt_rescore8 = 2;                        // rescore kernel: 0 lane per candidate, 1 eight lanes per candidate, 2 = 1 + rows staged through LDS
 
   // grow-only workspace
@@ -179,7 +181,8 @@ bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 38
 constexpr uint32_t F16_FILTER_MAX_DIM = 3072;
 constexpr uint32_t I8W_TILE_ROWS = 64;                // rows per tile of the int8 two-stage kernel (two 32-row blocks)
 constexpr uint32_t PAD_ROWS = 64;                     // zero rows every library-owned corpus / shadow is padded with: the largest tile
-bool i8_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 256; }   // int8 rows: stride % 256 == 0
+bool i8_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 256 || dim == 1024 || dim == 1280 || dim == 1536; }   // int8 rows: stride % 256 == 0
+constexpr uint32_t I8_FILTER_MAX_DIM = 1536;
 bool refine3_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256; }   // fp16 dims of the whole-row refine kernel
 
 nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
@@ -219,7 +222,7 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
     if (!(maxabs < 60000.f)) { (void)hipFree(c->shadow16); c->shadow16 = nullptr; }
     else c->fdim = sdim;
   }
-  if (c->dtype == NVDB_DTYPE_I8 && c->dim <= 768 && !i8_filter_dim(c->dim) && c->opt_f32_shadow) {
+  if (c->dtype == NVDB_DTYPE_I8 && c->dim <= I8_FILTER_MAX_DIM && !i8_filter_dim(c->dim) && c->opt_f32_shadow) {
     uint32_t sdim = 256;
     while (sdim < c->dim) sdim += 256;
     const size_t count = static_cast<size_t>(c->n) * sdim, pad = static_cast<size_t>(PAD_ROWS) * sdim + 4096;
@@ -267,9 +270,49 @@ nvdb_status launch_scan_exact_qg(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
   return NVDB_OK;
 }
 
+// dims the fp32-MFMA exact kernels are instantiated for (dim % 32 == 0: no scalar tail; 16 queries x dim floats in registers)
+bool exact_mfma_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128; }
+
+// The exact scan on the fp32 matrix cores (kernels_exact_mfma.h).  A query receives at most P * nslice * k list entries, nslice = 4 / (16-query
+// blocks of its group of 64, rounded up to 1, 2 or 4).
+template <int DT>
+nvdb_status launch_scan_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, const float* q32,
+                                   uint32_t nq, uint32_t k, const float* thr, uint32_t cap, uint32_t reserve) {
+  const uint32_t gy = (nq + 63) / 64;
+  const uint32_t last_blocks = (nq - (gy - 1) * 64 + 15) / 16;                    // 16-query blocks of the last (partial) group
+  const uint32_t nslice_max = last_blocks >= 3 ? 1u : (last_blocks == 2 ? 2u : 4u);
+  const uint32_t tiles = (row_hi - row_lo + EXACT_MFMA_ROWS - 1) / EXACT_MFMA_ROWS;
+  const uint32_t pmax = (cap > reserve + k * nslice_max) ? (cap - reserve) / (k * nslice_max) : 1;
+  uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);   // ~2 workgroups per CU in all (one resident at a time)
+  P = std::min(P, std::max<uint32_t>(1, tiles / 8));                                           // >= 8 tiles each
+  P = std::max<uint32_t>(1, std::min(P, pmax));
+  const dim3 grid(P, gy);
+  Cand* cand = static_cast<Cand*>(c->cand.p);
+  uint32_t* cnt = static_cast<uint32_t*>(c->cnt.p);
+  uint32_t* ovf = static_cast<uint32_t*>(c->overflow.p);
+#define NVDB_SCAN_MFMA(D) scan_exact_mfma_kernel<DT, D><<<grid, 256, 0, s>>>(c->rows, c->scales, row_lo, row_hi, q32, nq, k, thr, cand, cnt, cap, ovf)
+  switch (c->dim) {
+    case 768: NVDB_SCAN_MFMA(768); break;
+    case 512: NVDB_SCAN_MFMA(512); break;
+    case 384: NVDB_SCAN_MFMA(384); break;
+    case 256: NVDB_SCAN_MFMA(256); break;
+    default: NVDB_SCAN_MFMA(128); break;
+  }
+#undef NVDB_SCAN_MFMA
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
 // rows [row_lo,row_hi) x all nq queries; appends at most P*k entries per query
 nvdb_status launch_scan_exact(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, const float* q32,
                               uint32_t nq, uint32_t k, const float* thr, uint32_t cap, uint32_t reserve) {
+  if (k > WAVE_KMAX) return fail(c, NVDB_ERR_INTERNAL, "scan_exact: k beyond the wavefront-resident lists (64)");
+  // more than 8 queries, whole MFMA K-steps and enough rows for the tiles: the fp32 matrix cores (same bits, ~4x the rate)
+  if (c->opt_exact_mfma && nq > 8 && exact_mfma_dim(c->dim) && row_hi - row_lo >= 64u * EXACT_MFMA_ROWS) {
+    if (c->dtype == NVDB_DTYPE_F32) return launch_scan_exact_mfma<DT_F32>(c, s, row_lo, row_hi, q32, nq, k, thr, cap, reserve);
+    if (c->dtype == NVDB_DTYPE_F16) return launch_scan_exact_mfma<DT_F16>(c, s, row_lo, row_hi, q32, nq, k, thr, cap, reserve);
+    return launch_scan_exact_mfma<DT_I8>(c, s, row_lo, row_hi, q32, nq, k, thr, cap, reserve);
+  }
   uint32_t QG = nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1));
   while (QG > 1 && static_cast<size_t>(QG) * (((c->dim + 3u) & ~3u) * 4 + 4 * 64 * 8 + 16) > 60 * 1024) QG >>= 1;   // LDS budget
   if (static_cast<size_t>((c->dim + 3u) & ~3u) * 4 + 4 * 64 * 8 + 16 > 60 * 1024) return fail(c, NVDB_ERR_UNSUPPORTED, "dim too large for the exact kernel's LDS query staging (max ~14800)");
@@ -642,6 +685,42 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   return NVDB_OK;
 }
 
+// int8, 768 < dim <= 1536: the two-stage kernel on 32-row tiles with one 32-query block per wave (128 queries per workgroup);
+// the reference takes any dim (src/simd_dot.cpp:160-213)
+template <int DIM>
+nvdb_status launch_filter_i8w_big_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
+                                      uint32_t nq_pad, uint32_t cap) {
+  constexpr size_t lds = static_cast<size_t>(3) * (FILTER_ROWS * DIM + 4 * 1024);
+  uint32_t nwg = (static_cast<uint32_t>(c->num_cu) / QT) * QT;
+  if (nwg == 0) nwg = QT;
+  nvdb_status st;
+  if ((row_hi - row_lo) % FILTER_ROWS) return fail(c, NVDB_ERR_INTERNAL, "int8 kernel: row range is not a multiple of its 32-row tile");
+  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+  const signed char* qhi = static_cast<const signed char*>(c->q16.p);
+  const signed char* qlo = qhi + static_cast<size_t>(nq_pad) * DIM;
+  uint32_t* counts = static_cast<uint32_t*>(c->misc.p) + 4;
+  const bool sync = c->opt_sibling_sync && QT > 1 && QT <= 8 && (nwg & 7u) == 0 && ((nwg >> 3) % QT) == 0;
+  uint32_t* prog = nullptr;
+  if (sync && (st = next_prog_region(c, s, nwg, &prog))) return st;
+#define NVDB_I8BIG_LAUNCH(SYNCV)                                                                                                \
+  {                                                                                                                             \
+    const void* fn = reinterpret_cast<const void*>(filter_i8w_kernel<DIM, 1, 6, SYNCV, 1>);                                     \
+    if (!c->lds_attr_set.count(fn)) {                                                                                           \
+      HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
+      c->lds_attr_set.insert(fn);                                                                                               \
+    }                                                                                                                           \
+    hipExtLaunchKernelGGL((filter_i8w_kernel<DIM, 1, 6, SYNCV, 1>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, \
+                          filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, static_cast<const float*>(c->thr.p), \
+                          static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<const float*>(c->qdelta.p), \
+                          static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, FILTER_ROWS), prog,                              \
+                          static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), counts);       \
+  }
+  if (sync) NVDB_I8BIG_LAUNCH(true) else NVDB_I8BIG_LAUNCH(false)
+#undef NVDB_I8BIG_LAUNCH
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
 template <int DIM>
 nvdb_status launch_boot_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap) {
   constexpr size_t lds = static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * DIM + 4 * 1024);
@@ -681,7 +760,7 @@ bool i8_two_stage(const nvdb_hip_ctx* c) { return c->dtype == NVDB_DTYPE_I8 && c
 
 // NB = 32-query blocks per wave: 1 for nq <= 128 (HBM-bound regime) and for the two-plane int8 kernel, else 2
 uint32_t filter_nb(const nvdb_hip_ctx* c, uint32_t nq) {
-  if (c->dtype == NVDB_DTYPE_I8 && !i8_two_stage(c)) return 1u;
+  if (c->dtype == NVDB_DTYPE_I8 && (!i8_two_stage(c) || c->fdim > 768)) return 1u;   // two-plane kernel; dims > 768: 32 queries per wave
   if (c->dtype != NVDB_DTYPE_I8 && c->fdim > 768) return 1u;          // 16-row-tile build: 128 queries per workgroup
   return nq <= 128 ? 1u : 2u;
 }
@@ -690,6 +769,9 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
   const uint32_t nb = filter_nb(c, nq);
   if (c->dtype == NVDB_DTYPE_I8) {
     const uint32_t nq_pad = QT * 128u * nb;
+    if (c->fdim == 1024) return launch_filter_i8w_big_dim<1024>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->fdim == 1280) return launch_filter_i8w_big_dim<1280>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->fdim == 1536) return launch_filter_i8w_big_dim<1536>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (i8_two_stage(c)) {
 #define NVDB_I8W_DIM(D) if (c->fdim == D) return nb == 2 ? launch_filter_i8w_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap) : launch_filter_i8w_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap)
       NVDB_I8W_DIM(768); NVDB_I8W_DIM(512); NVDB_I8W_DIM(256);
@@ -722,6 +804,29 @@ nvdb_status launch_scores_exact_qg(nvdb_hip_ctx* c, hipStream_t s, const float* 
   else if (c->dtype == NVDB_DTYPE_F16) { if (al) NVDB_LAUNCH_SC(DT_F16, true); else NVDB_LAUNCH_SC(DT_F16, false); }
   else { if (al) NVDB_LAUNCH_SC(DT_I8, true); else NVDB_LAUNCH_SC(DT_I8, false); }
 #undef NVDB_LAUNCH_SC
+  HIPCHK(c, hipGetLastError());
+  return NVDB_OK;
+}
+
+// the same score matrix from the fp32 matrix cores (kernels_exact_mfma.h)
+nvdb_status launch_scores_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uint32_t nq, float* out, uint64_t ld) {
+  const uint32_t n = static_cast<uint32_t>(c->n);
+  const uint32_t gy = (nq + 63) / 64, tiles = (n + EXACT_MFMA_ROWS - 1) / EXACT_MFMA_ROWS;
+  uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);
+  P = std::max<uint32_t>(1, std::min(P, tiles / 8));
+  const dim3 grid(P, gy);
+#define NVDB_SC_MFMA(DT, D) scores_exact_mfma_kernel<DT, D><<<grid, 256, 0, s>>>(c->rows, c->scales, n, q32, nq, out, ld)
+#define NVDB_SC_MFMA_DT(DT)                                                                                       \
+  switch (c->dim) {                                                                                              \
+    case 768: NVDB_SC_MFMA(DT, 768); break;                                                                      \
+    case 512: NVDB_SC_MFMA(DT, 512); break;                                                                      \
+    case 384: NVDB_SC_MFMA(DT, 384); break;                                                                      \
+    case 256: NVDB_SC_MFMA(DT, 256); break;                                                                      \
+    default: NVDB_SC_MFMA(DT, 128); break;                                                                       \
+  }
+  if (c->dtype == NVDB_DTYPE_F32) NVDB_SC_MFMA_DT(DT_F32) else if (c->dtype == NVDB_DTYPE_F16) NVDB_SC_MFMA_DT(DT_F16) else NVDB_SC_MFMA_DT(DT_I8)
+#undef NVDB_SC_MFMA_DT
+#undef NVDB_SC_MFMA
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -765,7 +870,8 @@ nvdb_status search_largek(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, ui
     const uint32_t b = std::min(QB, nq - q0);
     const float* q = dev_q + static_cast<size_t>(q0) * c->dim;
     radix_init_kernel<<<b, 256, 0, s>>>(rst, hist, b, k_eff);
-    switch (QG) {
+    if (c->opt_exact_mfma && b > 8 && exact_mfma_dim(c->dim) && n >= 64u * EXACT_MFMA_ROWS) st = launch_scores_exact_mfma(c, s, q, b, scores, ld);
+    else switch (QG) {
       case 8: st = launch_scores_exact_qg<8>(c, s, q, b, scores, ld); break;
       case 4: st = launch_scores_exact_qg<4>(c, s, q, b, scores, ld); break;
       case 2: st = launch_scores_exact_qg<2>(c, s, q, b, scores, ld); break;
@@ -800,12 +906,13 @@ hipEvent_t get_event(nvdb_hip_ctx* c, size_t idx) {
 
 // Enqueue one whole search of nq (<= 2048) queries resident at dev_q.  No host synchronisation.
 nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint32_t nq, uint32_t k, uint64_t* dev_out_ids,
-                        float* dev_out_scores, int force_path, bool time_filter, uint32_t cap_override = 0) {
+                        float* dev_out_scores, int force_path, bool time_filter, uint32_t cap_override = 0, bool sticky = true) {
+  const int final_mode = sticky ? 1 : 3;          // select_kernel: 3 = final select without folding into the sticky self-check words
   const uint32_t k_eff = static_cast<uint32_t>(std::min<uint64_t>(k, c->n));
   const uint32_t n = static_cast<uint32_t>(c->n);
   int path = force_path ? force_path : static_cast<int>(c->opt_path);
   if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
-  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 3072 or an int8 corpus with dim <= 768");
+  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 3072 or an int8 corpus with dim <= 1536");
 
   uint32_t cap = cap_override ? cap_override : c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : std::max<uint32_t>(c->cap_hint, nq <= 64 ? SELECT_MAX_CAP : 2048u);
   cap = std::min(cap, SELECT_MAX_CAP);
@@ -815,7 +922,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // Anything else beyond the wavefront lists' 64 entries takes the any-k path.
   const bool k_wide = k_eff > WAVE_KMAX;
   const bool wide_on_filter = k_wide && path == 2 && force_path != 1 && k_eff <= FILTER_KMAX && c->opt_mfma_boot &&
-                              (c->dtype == NVDB_DTYPE_I8 || c->fdim <= 768) && c->n >= 2ull * FILTER_ROWS * 8 * k_eff;
+                              c->fdim <= 768 && c->n >= 2ull * FILTER_ROWS * 8 * k_eff;
   if (wide_on_filter) cap = SELECT_MAX_CAP;
   // queries per filter workgroup: 256 / 128, or 64 on the K-split build (dims > 1536)
   const uint32_t QPB = (c->dtype != NVDB_DTYPE_I8 && c->fdim > 1536) ? 64u : 128u * filter_nb(c, nq);
@@ -850,7 +957,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   if (path == 1) {
     if ((st = launch_scan_exact(c, s, 0, n, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
     c->stats.chunks = 1; c->stats.rows_scanned = c->n;
-    return launch_select(c, s, nq, cap, k_eff, nullptr, 1, dev_out_ids, dev_out_scores, k);
+    return launch_select(c, s, nq, cap, k_eff, nullptr, final_mode, dev_out_ids, dev_out_scores, k);
   }
 
   // ---- path 2: MFMA filter ----------------------------------------------------------------------
@@ -881,7 +988,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // chunk boundaries are whole tiles of the streaming kernel: 64 rows for the int8 two-stage kernel and for the m16
   // fp16 build at d <= 384, 32 otherwise
   const bool f16_wide_tiles = c->dtype != NVDB_DTYPE_I8 && c->fdim <= 384 && filter_nb(c, nq) == 2 && c->opt_mfma16;
-  const uint32_t tile_rows = (i8_two_stage(c) || f16_wide_tiles) ? I8W_TILE_ROWS : FILTER_ROWS;
+  const uint32_t tile_rows = ((i8_two_stage(c) && c->fdim <= 768) || f16_wide_tiles) ? I8W_TILE_ROWS : FILTER_ROWS;
   const uint32_t n_al = padded ? (n + tile_rows - 1) / tile_rows * tile_rows : n / tile_rows * tile_rows;
   uint32_t r = 0;
   uint64_t size;
@@ -890,7 +997,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // what its slowest wave costs (profiles/r01d_i8_growth_sweep.txt)
   // (with the first-stage survivors finished after the stream a flagged value costs little: 6 and a 1024-tile bootstrap on big
   // corpora, profiles/r02_i8_boot_growth_sweep.txt; the in-loop second stage wants 3)
-  const bool i8_big = i8_two_stage(c) && nq > 128;
+  const bool i8_big = i8_two_stage(c) && nq > 128 && c->fdim <= 768;
   const bool i8_log = i8_big && c->opt_i8_pipe && !c->opt_i8_defer && !c->i8_scales_signed && !c->opt_i8_waves8 && c->n >= 64ull * FILTER_ROWS * 1024;
   uint64_t growth = c->opt_growth > 0 ? static_cast<uint64_t>(c->opt_growth) : (i8_log ? 6u : i8_big ? 3u : 8u);
   if (k_wide) growth = std::max<uint64_t>(2, std::min<uint64_t>(growth, cap / (3ull * k_eff)));     // k * (growth - 1) + k + band <= cap
@@ -902,7 +1009,13 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t boot_rows = FILTER_ROWS * boot_tiles;
   const bool mfma_boot = c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
                          boot_rows / FILTER_ROWS <= cap &&
-                         (c->dtype == NVDB_DTYPE_I8 || c->fdim <= 768);    // no bootstrap build of the 16-row-tile kernel: exact bootstrap chunk
+                         c->fdim <= 768;    // no bootstrap build of the 16-row-tile fp16 kernel / the 32-query int8 kernel: exact bootstrap chunk
+  if (k_wide && !mfma_boot) {
+    // 64 < k on the filter path needs the MFMA bootstrap (the exact bootstrap chunk's wavefront lists hold 64 entries);
+    // e.g. option boot_tiles larger than the corpus: the any-k path takes the search instead
+    c->stats.path = 3; c->last_filter = false;
+    return search_largek(c, s, dev_q, nq, k, dev_out_ids, dev_out_scores);
+  }
   // permuted tile order needs the bootstrap whose entries are discarded (the exact bootstrap chunk keeps rows [0, r))
   c->perm_on = c->opt_tile_permute && mfma_boot;
   if (mfma_boot) {
@@ -955,7 +1068,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     c->stats.rows_scanned += static_cast<uint64_t>(n - n_al) * QT;
   }
   if ((st = launch_rescore(c, s, dev_q, nq, cap))) return st;
-  return launch_select(c, s, nq, cap, k_eff, nullptr, 1, dev_out_ids, dev_out_scores, k);
+  return launch_select(c, s, nq, cap, k_eff, nullptr, final_mode, dev_out_ids, dev_out_scores, k);
 }
 
 }  // namespace
@@ -1141,6 +1254,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "debug_rows") { c->dbg_rows = value < 0 ? 0 : value; }
 #endif
   else if (k == "waves8") { c->opt_waves8 = value ? 1 : 0; }
+  else if (k == "exact_mfma") { c->opt_exact_mfma = value ? 1 : 0; }
   else if (k == "tile_permute") { c->opt_tile_permute = value ? 1 : 0; }
   else if (k == "rescore8") { c->opt_rescore8 = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
@@ -1171,7 +1285,9 @@ nvdb_status nvdb_hip_search_batch_dev(nvdb_hip_ctx* c, const float* dev_q, uint3
   return search_core(c, s, dev_q, nq, k, dev_out_ids, dev_out_scores, 0, false);
 }
 
-nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
+// own_only: the host API's view of ITS OWN last search (misc[0], [1], per-query flags); the sticky words that device-API
+// searches left for the caller's next nvdb_hip_search_check are neither read into the verdict nor cleared
+static nvdb_status search_check_impl(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats, bool own_only) {
   if (!c) return NVDB_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   // caller has synchronised its stream; read the self-check words
@@ -1180,6 +1296,7 @@ nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   if (c->last_nq) HIPCHK(c, hipMemcpy(ovf.data(), c->overflow.p, c->last_nq * 4, hipMemcpyDeviceToHost));
   if (c->misc.p) {
     HIPCHK(c, hipMemcpy(misc, c->misc.p, 64, hipMemcpyDeviceToHost));
+    if (own_only) misc[12] = misc[13] = misc[14] = 0;
     const uint32_t zero[3] = {0, 0, 0};             // sticky words (select_kernel): what ANY search since the last check found
     if (misc[12] | misc[13] | misc[14]) HIPCHK(c, hipMemcpy(static_cast<uint32_t*>(c->misc.p) + 12, zero, 12, hipMemcpyHostToDevice));
   }
@@ -1217,6 +1334,8 @@ nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) {
   if (misc[12] | misc[14]) return fail(c, NVDB_ERR_INTERNAL, "candidate list overflow in an earlier search since the last check");
   return NVDB_OK;
 }
+
+nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) { return search_check_impl(c, stats, false); }
 
 nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_t nq, uint32_t k, uint64_t* out_ids,
                                   float* out_scores, uint32_t* out_k_eff, nvdb_hip_timing* timing) {
@@ -1258,7 +1377,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     const float* dq = static_cast<const float*>(c->q32.p);
     uint64_t* oi = static_cast<uint64_t*>(c->out_ids.p);
     float* os = static_cast<float*>(c->out_scores.p);
-    if ((st = search_core(c, s, dq, nq, k, oi, os, 0, timing != nullptr))) return st;
+    if ((st = search_core(c, s, dq, nq, k, oi, os, 0, timing != nullptr, 0, false))) return st;
     HIPCHK(c, hipEventRecord(e2, s));
     auto fetch = [&]() -> nvdb_status {
       HIPCHK(c, hipMemcpyAsync(pin_status, c->misc.p, 32, hipMemcpyDeviceToHost, s));
@@ -1275,21 +1394,19 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
       // the longest candidate lists the select kernel can sort (near-duplicate-heavy corpora: thousands of rows inside
       // the filter's error band of the k-th score; re-scoring them is cheap, only the list was too short), and if that
       // is still not enough, or the bound itself was violated, on the always-correct exact path
-      nvdb_status chk = nvdb_hip_search_check(c, &part);
+      nvdb_status chk = search_check_impl(c, &part, true);
       if (chk == NVDB_ERR_HIP) return chk;
       bool done = false;
       if (part.path == 2 && !pin_status[0] && c->last_cap < SELECT_MAX_CAP) {
-        if ((st = search_core(c, s, dq, nq, k, oi, os, 2, false, SELECT_MAX_CAP))) return st;
+        if ((st = search_core(c, s, dq, nq, k, oi, os, 2, false, SELECT_MAX_CAP, false))) return st;
         if ((st = fetch())) return st;
         done = !(pin_status[0] | pin_status[1] | pin_status[6]);
         if (done) c->cap_hint = SELECT_MAX_CAP;
       }
       if (!done) {
-        if ((st = search_core(c, s, dq, nq, k, oi, os, 1, false))) return st;
+        if ((st = search_core(c, s, dq, nq, k, oi, os, 1, false, 0, false))) return st;
         if ((st = fetch())) return st;
       }
-      // handled here: do not leave the sticky self-check words set for a later nvdb_hip_search_check
-      HIPCHK(c, hipMemsetAsync(static_cast<uint32_t*>(c->misc.p) + 12, 0, 12, s));
       c->stats = part;
     } else {
       part.i8_stage1_tiles = pin_status[4]; part.i8_stage2_blocks = pin_status[5];
@@ -1325,28 +1442,27 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     const float* dq = static_cast<const float*>(c->q32.p) + static_cast<size_t>(q0) * c->dim;
     uint64_t* oi = static_cast<uint64_t*>(c->out_ids.p) + static_cast<size_t>(q0) * k;
     float* os = static_cast<float*>(c->out_scores.p) + static_cast<size_t>(q0) * k;
-    if ((st = search_core(c, s, dq, b, k, oi, os, 0, timing != nullptr))) return st;
+    if ((st = search_core(c, s, dq, b, k, oi, os, 0, timing != nullptr, 0, false))) return st;
     HIPCHK(c, hipStreamSynchronize(s));
     nvdb_hip_scan_stats part{};
-    nvdb_status chk = nvdb_hip_search_check(c, &part);
+    nvdb_status chk = search_check_impl(c, &part, true);
     if (chk == NVDB_ERR_HIP) return chk;
     if (chk == NVDB_ERR_INTERNAL) {
       // self-check tripped: longest lists first, then the always-correct exact path (see the small-call path above)
       bool done = false;
       if (part.path == 2 && !part.bound_violations && c->last_cap < SELECT_MAX_CAP) {
-        if ((st = search_core(c, s, dq, b, k, oi, os, 2, false, SELECT_MAX_CAP))) return st;
+        if ((st = search_core(c, s, dq, b, k, oi, os, 2, false, SELECT_MAX_CAP, false))) return st;
         HIPCHK(c, hipStreamSynchronize(s));
         nvdb_hip_scan_stats again{};
-        const nvdb_status chk2 = nvdb_hip_search_check(c, &again);
+        const nvdb_status chk2 = search_check_impl(c, &again, true);
         if (chk2 == NVDB_ERR_HIP) return chk2;
         done = (chk2 == NVDB_OK);
         if (done) c->cap_hint = SELECT_MAX_CAP;
       }
       if (!done) {
-        if ((st = search_core(c, s, dq, b, k, oi, os, 1, false))) return st;
+        if ((st = search_core(c, s, dq, b, k, oi, os, 1, false, 0, false))) return st;
         HIPCHK(c, hipStreamSynchronize(s));
       }
-      HIPCHK(c, hipMemsetAsync(static_cast<uint32_t*>(c->misc.p) + 12, 0, 12, s));     // handled: clear the sticky self-check words
     }
     total.path = std::max(total.path, part.path);
     total.chunks += part.chunks; total.rows_scanned += part.rows_scanned; total.candidates += part.candidates;
@@ -1773,6 +1889,23 @@ static nvdb_status launch_refine(nvdb_hip_ctx* c, hipStream_t s, const float* dq
     }
     if (c->dim == 768) NVDB_REFINE3(768) else if (c->dim == 512) NVDB_REFINE3(512) else if (c->dim == 384) NVDB_REFINE3(384) else NVDB_REFINE3(256)
 #undef NVDB_REFINE3
+    HIPCHK(c, hipGetLastError());
+    return NVDB_OK;
+  }
+  // v3 for long fp16 rows (2 KB / 3 KB): query in LDS, 8 whole rows per wave and step
+  if (c->opt_refine_v2 >= 2 && c->dtype == NVDB_DTYPE_F16 && (c->dim == 1024 || c->dim == 1536)) {
+#define NVDB_REFINE3L(D)                                                                                                       \
+    {                                                                                                                          \
+      constexpr size_t lds = static_cast<size_t>(REFINE3_WAVES) * REFINE3L_ROWS * (D * 2 + 16) + D * 4;                        \
+      const void* fn = reinterpret_cast<const void*>(refine_l2_rows_long_kernel<D>);                                           \
+      if (!c->lds_attr_set.count(fn)) {                                                                                        \
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                 \
+        c->lds_attr_set.insert(fn);                                                                                            \
+      }                                                                                                                        \
+      refine_l2_rows_long_kernel<D><<<Q, 64 * REFINE3_WAVES, lds, s>>>(c->rows, c->n, dq, dc, R, K, doi, dod);                  \
+    }
+    if (c->dim == 1024) NVDB_REFINE3L(1024) else NVDB_REFINE3L(1536)
+#undef NVDB_REFINE3L
     HIPCHK(c, hipGetLastError());
     return NVDB_OK;
   }

@@ -258,6 +258,54 @@ def test_int8_other_dims_through_the_zero_padded_shadow(ctx, oracle, d, nq, k):
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[2][0], res[2][1], k, f"i8-pad/d{d}")
 
 
+@pytest.mark.parametrize("d,nq,k", [(1536, 300, 10), (1024, 64, 10), (1280, 130, 5), (1000, 200, 10), (1100, 33, 64), (1536, 1, 10), (1400, 1024, 10)])
+def test_int8_dims_up_to_1536_on_integer_mfma(ctx, oracle, d, nq, k):
+    """768 < dim <= 1536 (the reference takes any dim, src/simd_dot.cpp:160-213): the two-stage int8 kernel on 32-row tiles
+    with 32 queries per wave, K-step count up to 48; dims that are not 1024 / 1280 / 1536 stream a zero-padded copy.
+    Results come from the original rows either way."""
+    n = 70_000 + 13
+    base32 = nvdb_amd.synth_rows_f32(SEED + 140 + d, 0, n, d)
+    base, scales = oracle.quantize_i8(base32)
+    queries = nvdb_amd.synth_rows_f32(SEED + 141 + d, 0, nq, d)
+    if nq > 4:
+        queries[3] *= 37.0                                        # a scaled query: thresholds live in the query's own units
+        queries[4, : d // 2] = 0.0                                # and a half-empty one
+    ctx.upload_corpus(base, po.DT_I8, scales)
+    ctx.set_option("path", 2)
+    ids, sc = ctx.search_batch(queries, k)
+    st = ctx.stats()
+    ctx.set_option("path", 1)
+    ei, es = ctx.search_batch(queries, k)
+    ctx.set_option("path", 0)
+    assert st["path"] == 2 and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    assert np.array_equal(ids, ei) and np.array_equal(sc.view(np.uint32), es.view(np.uint32))
+    sub = slice(0, min(nq, 12))
+    _check_against_oracle(oracle, base, po.DT_I8, scales, queries[sub], ids[sub], sc[sub], k, f"i8 d={d}")
+
+
+def test_int8_big_dim_flat_queries_and_dense_blocks(ctx, oracle):
+    """d = 1536 with queries whose components all sit at full magnitude (the hi plane's L1 cap of prep_q8_kernel quantises them
+    more coarsely, so that |H| < 2^23 and (H << 7) + L stays inside int32 at any dim) against rows of all +-127; plus a
+    near-duplicate block so that many values of one (row block, query block) pass the first stage (lo-plane MFMAs)."""
+    n, d, nq, k = 40_000, 1536, 140, 10
+    rs = np.random.RandomState(77)
+    base32 = nvdb_amd.synth_rows_f32(SEED + 150, 0, n, d)
+    base, scales = oracle.quantize_i8(base32)
+    base[100] = 127; base[101] = -127; base[102] = np.where(rs.rand(d) < 0.5, 127, -127).astype(np.int8)
+    base[2000:2040] = base[1999]                                  # exact duplicates inside one tile
+    scales[2000:2040] = scales[1999]
+    queries = nvdb_amd.synth_rows_f32(SEED + 151, 0, nq, d)
+    queries[0] = 1.0; queries[1] = -1.0; queries[2] = np.sign(base[102]).astype(np.float32)
+    queries[5] = base32[1999]
+    ctx.upload_corpus(base, po.DT_I8, scales)
+    ctx.set_option("path", 2)
+    ids, sc = ctx.search_batch(queries, k)
+    st = ctx.stats()
+    ctx.set_option("path", 0)
+    assert st["path"] == 2 and st["bound_violations"] == 0, st
+    _check_against_oracle(oracle, base, po.DT_I8, scales, queries[:8], ids[:8], sc[:8], k, "i8 d=1536 flat")
+
+
 def test_int8_two_stage_kernel_with_a_negative_row_scale(ctx, oracle):
     """A negative row scale is never produced by the reference quantiser but is legal in the file format; both
     stages of the kernel are sign-agnostic (per-value products; |scale| in the lo-plane bound)."""
@@ -567,7 +615,8 @@ def test_device_merge_matches_host_merge(ctx):
 
 # ----------------------------------------------------------------------------- refine
 @pytest.mark.parametrize("tag,d,R,K", [("f16", 768, 1024, 10), ("f16", 384, 500, 10), ("f32", 768, 300, 64),
-                                       ("f16", 100, 77, 5), ("f32", 37, 40, 3)])
+                                       ("f16", 100, 77, 5), ("f32", 37, 40, 3), ("f16", 1536, 1024, 10), ("f16", 1024, 333, 64),
+                                       ("f16", 1536, 17, 3)])
 def test_refine_matches_restated_reference_order(ctx, oracle, tag, d, R, K):
     n, Q = 30000, 40
     rs = np.random.RandomState(d + R)
@@ -1041,6 +1090,136 @@ def test_adopted_corpus_and_device_buffers(oracle, tag):
         oid, od = oracle.refine(base, po.DT_F16 if tag == "f16" else po.DT_F32, queries, cand, k, mode=0)
         assert np.array_equal(t_oi.cpu().numpy().view(np.uint32), oid) and np.array_equal(t_od.cpu().numpy().view(np.uint32), od.view(np.uint32))
         ctx.close()
+
+
+def test_host_api_leaves_the_device_api_sticky_flags_alone(oracle):
+    """Sticky self-check words (misc[12..14]) belong to the device API: a host-API search on the same context -- clean or
+    one that trips and recovers by itself -- must neither erase what an earlier, unchecked device-API search left, nor
+    be failed by it (the nq > 1024 host path used to redo every sub-batch on the exact path)."""
+    import torch
+    n, d, k = 40000, 768, 10
+    base32 = nvdb_amd.synth_rows_f32(SEED + 11, 0, n, d)
+    q = nvdb_amd.synth_rows_f32(SEED + 12, 0, 1200, d)
+    base = oracle.f32_to_f16(base32[np.argsort(base32 @ q[0])])          # ascending similarity to query 0 (adversarial for it alone)
+    c = nvdb_amd.HipContext(0)
+    c.upload_corpus(base, po.DT_F16)
+    dev = torch.device("cuda", 0)
+    t_q = torch.from_numpy(q[:16]).to(dev)
+    t_ids = torch.empty((16, k), dtype=torch.int64, device=dev)
+    t_sc = torch.empty((16, k), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    c.set_option("path", 2); c.set_option("cand_cap", 64); c.set_option("tile_permute", 0)
+    c.search_batch_dev(t_q.data_ptr(), 16, k, t_ids.data_ptr(), t_sc.data_ptr(), None)      # overflows: sticky flag set, not checked yet
+    torch.cuda.synchronize()
+    c.set_option("cand_cap", 0); c.set_option("tile_permute", 1); c.set_option("path", 0)
+    ids, sc = c.search_batch(q[100:], k)                                 # host API, 1100 other queries: two sub-batches, both clean
+    st = c.stats()
+    assert st["path"] == 2 and st["overflow_queries"] == 0, st          # not dragged onto the exact path by the stale flag
+    oid, osc = oracle.flat_topk(base, po.DT_F16, q[100:124], k)
+    assert np.array_equal(ids[:24], oid) and np.array_equal(sc[:24].view(np.uint32), osc.view(np.uint32))
+    c.set_option("path", 2); c.set_option("cand_cap", 64); c.set_option("tile_permute", 0)
+    c.search_batch(q[:16], k)                                            # a host search that trips and recovers by itself
+    c.set_option("cand_cap", 0); c.set_option("tile_permute", 1); c.set_option("path", 0)
+    with pytest.raises(nvdb_amd.NvdbError) as e:                        # the device-API search's flag is still there
+        c.search_check()
+    assert e.value.status == 5
+    assert c.search_check()["sticky_overflow"] == 0                     # ... and the check cleared it
+    c.close()
+
+
+def test_wide_k_without_the_mfma_bootstrap_takes_the_any_k_path(oracle):
+    """64 < k <= 1024 rides the filter path only with the MFMA bootstrap; when that is unavailable (boot_tiles larger
+    than the corpus here) the search must go to the any-k path, not to the exact bootstrap chunk whose wavefront lists
+    hold 64 entries."""
+    n, d, nq, k = 60000, 768, 40, 100
+    c = nvdb_amd.HipContext(0)
+    c.generate_corpus(SEED + 97, n, d, nvdb_amd.DT_F16)
+    queries = nvdb_amd.synth_rows_f32(SEED + 98, 0, nq, d)
+    c.set_option("path", 2)
+    c.set_option("boot_tiles", 4096)
+    c.set_option("chunk0_rows", 4096)
+    ids, sc = c.search_batch(queries, k)
+    assert c.stats()["path"] == 3
+    base, _ = nvdb_amd.synth_corpus(SEED + 97, 0, n, d, nvdb_amd.DT_F16)
+    oid, osc = oracle.flat_topk(base, po.DT_F16, queries[:8], k)
+    assert np.array_equal(ids[:8], oid) and np.array_equal(sc[:8].view(np.uint32), osc.view(np.uint32))
+    c.close()
+
+
+def test_int8_corpus_with_a_huge_row_scale_takes_the_unbiased_build(oracle):
+    """A row scale beyond ~1e30 would make the biased-accumulator test compute inf - inf; such corpora are routed to the
+    in-loop build like corpora with negative scales."""
+    n, d, nq, k = 600_000, 768, 200, 10
+    c = nvdb_amd.HipContext(0)
+    base, scales = nvdb_amd.synth_corpus(SEED + 99, 0, n, d, nvdb_amd.DT_I8)
+    scales = scales.copy()
+    scales[12345] = np.float32(3e31)
+    c.upload_corpus(base, po.DT_I8, scales)
+    queries = nvdb_amd.synth_rows_f32(SEED + 98, 0, nq, d)
+    c.set_option("path", 2)
+    ids, sc = c.search_batch(queries, k)
+    st = c.stats()
+    c.set_option("path", 1)
+    ei, es = c.search_batch(queries, k)
+    c.close()
+    assert np.array_equal(ids, ei) and np.array_equal(sc.view(np.uint32), es.view(np.uint32))
+    oid, osc = oracle.flat_topk(base, po.DT_I8, queries[:4], k, scales)
+    assert np.array_equal(ids[:4], oid) and np.array_equal(sc[:4].view(np.uint32), osc.view(np.uint32))
+
+
+@pytest.mark.parametrize("tag", ["f16", "f32", "i8"])
+@pytest.mark.parametrize("d,nq", [(768, 64), (768, 9), (768, 33), (384, 100), (128, 17), (512, 48), (256, 130)])
+def test_exact_scores_on_the_fp32_matrix_cores(oracle, tag, d, nq):
+    """Path 1 with more than 8 queries on dims that are whole MFMA K-steps runs on v_mfma_f32_16x16x4_f32 (eight accumulator
+    tiles = the reference's eight stride-8 fma chains, kernels_exact_mfma.h): ids and score BITS must equal the VALU kernels'
+    (option exact_mfma = 0) and the oracle's, including rows / queries with zeros, huge and tiny magnitudes (subnormal
+    products and sums) and a row count that is not a multiple of the 16-row tile."""
+    n, k = 20_000 + 7, 10
+    rs = np.random.RandomState(d + nq)
+    base32 = nvdb_amd.synth_rows_f32(SEED + 160, 0, n, d)
+    base32[11] = 0.0
+    base32[12] *= np.float32(1e-30); base32[13] *= np.float32(3e18); base32[14, ::2] = 0.0
+    base32[15] = base32[16]                                              # an exact tie
+    base32[500:600] *= (np.float32(10.0) ** rs.randint(-20, 8, size=(100, 1))).astype(np.float32)
+    base, dt, scales = _as_dtype(oracle, base32, tag)
+    queries = nvdb_amd.synth_rows_f32(SEED + 161, 0, nq, d)
+    queries[1] *= np.float32(1e-12); queries[2] *= np.float32(1e15); queries[3, : d // 2] = 0.0; queries[4] = -queries[4]
+    queries[5] = base32[15]
+    c = nvdb_amd.HipContext(0)
+    c.upload_corpus(base, dt, scales)
+    c.set_option("path", 1)
+    res = {}
+    for mf in (1, 0):
+        c.set_option("exact_mfma", mf)
+        res[mf] = c.search_batch(queries, k)
+        assert c.stats()["path"] == 1
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))
+    sub = np.r_[0:8, nq - 1]
+    _check_against_oracle(oracle, base, dt, scales, queries[sub], res[1][0][sub], res[1][1][sub], k, f"exact-mfma/{tag}/d{d}")
+    # the any-k path's score matrix comes from the same tiles (k = 100 on 20K rows is off the filter path)
+    for mf in (1, 0):
+        c.set_option("exact_mfma", mf)
+        res[mf] = c.search_batch(queries, 100)
+        assert c.stats()["path"] == 3
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))
+    c.close()
+
+
+def test_exact_mfma_pruned_by_thresholds_and_small_row_ranges(oracle):
+    """The MFMA scan as the filter path's helper: ragged tails / bootstrap chunks call it with per-query thresholds and
+    arbitrary row ranges; k = 64 fills the wavefront-sized lists; 3 query blocks leave one wave of the workgroup idle."""
+    n, d, nq, k = 9_000 + 5, 768, 40, 64
+    c = nvdb_amd.HipContext(0)
+    c.generate_corpus(SEED + 170, n, d, nvdb_amd.DT_F16)
+    base, _ = nvdb_amd.synth_corpus(SEED + 170, 0, n, d, nvdb_amd.DT_F16)
+    queries = nvdb_amd.synth_rows_f32(SEED + 171, 0, nq, d)
+    c.set_option("path", 1)
+    ids, sc = c.search_batch(queries, k)
+    c.set_option("exact_mfma", 0)
+    ei, es = c.search_batch(queries, k)
+    c.close()
+    assert np.array_equal(ids, ei) and np.array_equal(sc.view(np.uint32), es.view(np.uint32))
+    _check_against_oracle(oracle, base, po.DT_F16, None, queries[:6], ids[:6], sc[:6], k, "exact-mfma k=64")
 
 
 def test_randomised_cross_check():

@@ -4,9 +4,11 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, nvdb_amd, pyoracle as po
-N, D, Q, R, K = 2_900_000, 768, 10_000, int(os.environ.get("REFINE_K", 1024)), 10
+N, D, Q, R, K = int(os.environ.get("REFINE_N", 2_900_000)), int(os.environ.get("REFINE_D", 768)), int(os.environ.get("REFINE_Q", 10_000)), int(os.environ.get("REFINE_K", 1024)), 10
 ctx = nvdb_amd.HipContext(0)
-ctx.generate_corpus(20240613, N, D, nvdb_amd.DT_F16)
+DT = nvdb_amd.DT_F32 if os.environ.get("REFINE_DT") == "f32" else nvdb_amd.DT_F16
+BPE = 4 if DT == nvdb_amd.DT_F32 else 2
+ctx.generate_corpus(20240613, N, D, DT)
 queries = nvdb_amd.synth_rows_f32(20240614, 0, Q, D)
 rs = np.random.RandomState(1)
 cand = rs.randint(0, N, size=(Q, R)).astype(np.uint32)
@@ -29,9 +31,9 @@ uniq = np.unique(cand[sub][cand[sub] != 0xFFFFFFFF])
 remap = {int(u): i for i, u in enumerate(uniq)}
 base_sub = np.concatenate([ctx.download_rows(int(u), 1)[0] for u in uniq])
 c2 = np.array([[remap.get(int(v), 0xFFFFFFFF) if v != 0xFFFFFFFF else 0xFFFFFFFF for v in row] for row in cand[sub]], dtype=np.uint32)
-oid, od = orc.refine(base_sub, po.DT_F16, queries[sub], c2, K, mode=0)
+oid, od = orc.refine(base_sub, po.DT_F32 if BPE == 4 else po.DT_F16, queries[sub], c2, K, mode=0)
 ok = np.array_equal(uniq[oid], ids[sub]) and np.array_equal(od.view(np.uint32), dist[sub].view(np.uint32))
-gb = Q * R * 0.99 * D * 2 / 1e9
-print(json.dumps({"config": f"refine N={N} Q={Q} R={R} K={K} f16", "kernel_ms": best.kernel_ms, "h2d_ms": best.h2d_ms, "d2h_ms": best.d2h_ms,
+gb = Q * R * 0.99 * D * BPE / 1e9
+print(json.dumps({"config": f"refine N={N} d={D} Q={Q} R={R} K={K} {'f32' if BPE == 4 else 'f16'}", "kernel_ms": best.kernel_ms, "h2d_ms": best.h2d_ms, "d2h_ms": best.d2h_ms,
                   "us_per_query_kernel": best.kernel_ms * 1e3 / Q, "gather_GBps": gb / (best.kernel_ms * 1e-3), "hbm_frac": gb / (best.kernel_ms * 1e-3) / 8000.0,
                   "parity_vs_oracle_slice": bool(ok), "kernel_ms_by_variant": per_kernel}))

@@ -12,7 +12,7 @@ orc = po.Oracle(); ctx = nvdb_amd.HipContext(0)
 t0 = time.time(); fails = 0
 for ci in range(cases):
     tag = rs.choice(["f16", "f16", "f32"])
-    dim = int(rs.choice([8, 24, 100, 128, 200, 384, 512, 768, 768, 1000, 1536]))
+    dim = int(rs.choice([8, 24, 100, 128, 200, 384, 512, 768, 768, 1000, 1024, 1536, 1536]))
     n = int(rs.choice([1, 50, 1000, 20000, 60000]))
     Q = int(rs.choice([1, 3, 17, 40])); R = int(rs.choice([1, 7, 64, 65, 300, 700, 1024])); K = int(rs.choice([1, 10, 10, 33, 64]))
     dt = nvdb_amd.DT_F16 if tag == "f16" else nvdb_amd.DT_F32
