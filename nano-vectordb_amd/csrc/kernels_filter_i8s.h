@@ -129,6 +129,12 @@ __global__ __launch_bounds__(256, 1) void filter_i8s_kernel(
   // set 0 = block 0 of the current tile (filled during the first half, used in the second), set 1 = block 1 (filled during the
   // second half, used in the NEXT tile's first half -- which then touches nothing of this tile's stage: one barrier per tile)
   float scv[2][8], scc[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { scv[0][i] = scv[1][i] = 0.f; scc[0][i] = scc[1][i] = 0.f; }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc1[h][nb] = bias0;        // tile 0's first half "tests" block 1 of a tile that does not exist (ignored)
   float mx[NB][2];                                 // running max of H * scale per query block and 16-row half
   float4_t ar[RING];
 

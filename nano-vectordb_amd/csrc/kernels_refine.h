@@ -425,107 +425,10 @@ __global__ __launch_bounds__(64 * REFINE3_WAVES) void refine_l2_rows_kernel(cons
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// refine, version 3 for long fp16 rows (dim a multiple of 512: 1024 -> 2 KB rows, 1536 -> 3 KB rows): the same whole-row
-// requests -- per row RB / 1024 one-KB direct-to-LDS loads with a SCALAR row base -- and the same four lanes per row (the
-// reference's four accumulators, cuda_refine.cu:326-382).  What changes against refine_l2_rows_kernel:
-//   * a lane's share of the query would be DIM / 4 registers (384 at d = 1536), so the query lives in LDS (staged once per
-//     workgroup; lane (r, c) reads pair 4i + c with ds_read_b64: all rows of a wave read the same four addresses, a broadcast);
-//   * a wave asks for 8 rows per step, not 16: 8 x 3 KB is the same 24 KB slot, so the same 6 waves per CU (two workgroups of
-//     three; d = 1024: three workgroups) keep the same ~140 KB per CU on request; lanes 32..63 only help to issue the loads.
-// LDS image: row j at j * (RB + 16) (the 16 bytes of padding put the 8 rows on 8 x 4 distinct banks).
-// ------------------------------------------------------------------------------------------------
-constexpr int REFINE3L_ROWS = 8;
-
-template <int DIM>
-__global__ __launch_bounds__(64 * REFINE3_WAVES) void refine_l2_rows_long_kernel(const void* __restrict__ rows, uint64_t n, const float* __restrict__ queries,
-                                                                                 const uint32_t* __restrict__ cand, uint32_t R, uint32_t K,
-                                                                                 uint32_t* __restrict__ out_ids, float* __restrict__ out_dist) {
-  constexpr int W = REFINE3_WAVES, NR = REFINE3L_ROWS;
-  constexpr int RB = DIM * 2, NPC = RB / 1024, RBLOCK = RB + 16, SLOT = NR * RBLOCK, NPAIR = DIM / 8;
-  static_assert(RB % 1024 == 0 && NPC >= 2 && NPC <= 3 && 2 * (W * SLOT + DIM * 4 + 1600) <= 160 * 1024, "rows of 2 or 3 KB, two workgroups per CU");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float lds_d[W][64];
-  __shared__ uint32_t lds_id[W][64];
-  __shared__ uint32_t lds_cnt[W];
-  const uint32_t q = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = (lane >> 2) & (NR - 1), c = lane & 3;
-  const bool worker = lane < 4 * NR;                                  // lanes that own an accumulator of one of the step's rows
-  const uint32_t* __restrict__ cq = cand + static_cast<uint64_t>(q) * R;
-  char* myslot = smem + wave * SLOT;
-  float* qlds = reinterpret_cast<float*>(smem + W * SLOT);
-  const uint32_t lds_mine = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(myslot)));
-  const char* gbase = static_cast<const char*>(rows);
-
-  for (int i = threadIdx.x; i < DIM / 4; i += 64 * W)
-    reinterpret_cast<float4*>(qlds)[i] = reinterpret_cast<const float4*>(queries + static_cast<uint64_t>(q) * DIM)[i];
-  __syncthreads();
-
-  WaveTopKMin tk;
-  tk.d = 1e30f; tk.id = 0xFFFFFFFFu; tk.cnt = 0; tk.thr_d = 1e30f; tk.thr_id = 0xFFFFFFFFu;
-
-  const uint32_t voff = static_cast<uint32_t>(lane) * 16u;
-  const char* rd = myslot + r * RBLOCK + c * 4;                     // half2 pair 4i + c of row r: + 16 i
-  const float2* rq = reinterpret_cast<const float2*>(qlds) + c;     // query pair 4i + c: + 4 i (float2 units)
-
-  uint32_t idx = wave * NR + (lane & (NR - 1));
-  uint32_t ids_next = (idx < R) ? cq[idx] : 0xFFFFFFFFu;
-  for (uint32_t s0 = wave * NR; s0 < R; s0 += W * NR) {
-    const uint32_t ids = ids_next;                                    // lanes 0..7 (and their copies): candidate of row lane & 7
-    idx += W * NR;
-    ids_next = (idx < R) ? cq[idx] : 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const uint32_t sid = readlane_u(ids, j);
-      const bool ok = (sid != 0xFFFFFFFFu) && (static_cast<uint64_t>(sid) < n);           // cuda_refine.cu:437; wave-uniform
-      if (ok) {
-        const char* rowp = gbase + static_cast<uint64_t>(sid) * RB;
-#pragma unroll
-        for (int pc = 0; pc < NPC; ++pc) glds16_imm<0>(voff, rowp + pc * 1024, lds_mine + j * RBLOCK + pc * 1024);
-      }
-    }
-    const uint32_t my_id = static_cast<uint32_t>(__shfl(static_cast<int>(ids), r));
-    const bool valid = worker && (my_id != 0xFFFFFFFFu) && (static_cast<uint64_t>(my_id) < n);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float acc = 0.f;
-#pragma unroll 16
-    for (int i = 0; i < NPAIR; ++i) {
-      const uint32_t x = *reinterpret_cast<const uint32_t*>(rd + i * 16);
-      const float2 qq = rq[4 * i];
-      const float dx = q_minus_half_lo(x, qq.x);
-      const float dy = q_minus_half_hi(x, qq.y);
-      acc = __builtin_fmaf(dx, dx, acc);
-      acc = __builtin_fmaf(dy, dy, acc);
-    }
-    const float s1 = acc + __shfl_xor(acc, 1);
-    const float d = s1 + __shfl_xor(s1, 2);
-    unsigned long long m = __ballot(valid && c == 0 && wmin_accepts(tk, K, d, my_id));
-    while (m) {
-      const int L = __builtin_ctzll(m);
-      m &= m - 1;
-      const float cd = readlane_f(d, L);
-      const uint32_t cid = readlane_u(my_id, L);
-      if (wmin_accepts(tk, K, cd, cid)) wmin_insert(tk, K, cd, cid, lane);
-    }
-  }
-  lds_d[wave][lane] = tk.d; lds_id[wave][lane] = tk.id;
-  if (lane == 0) lds_cnt[wave] = tk.cnt;
-  __syncthreads();
-  if (wave != 0) return;
-  for (int w = 1; w < W; ++w) {
-    const uint32_t cn = lds_cnt[w];
-    for (uint32_t j = 0; j < cn; ++j) {
-      const float cd = lds_d[w][j];
-      const uint32_t cid = lds_id[w][j];
-      if (wmin_accepts(tk, K, cd, cid)) wmin_insert(tk, K, cd, cid, lane);
-    }
-  }
-  if (static_cast<uint32_t>(lane) < K) {
-    const bool have = static_cast<uint32_t>(lane) < tk.cnt;
-    out_ids[static_cast<uint64_t>(q) * K + lane] = have ? tk.id : 0xFFFFFFFFu;
-    if (out_dist) out_dist[static_cast<uint64_t>(q) * K + lane] = have ? tk.d : 1e30f;
-  }
-}
-
+// Long fp16 rows (d = 1024 / 1536: 2 KB / 3 KB) stay on refine_l2_lds_kernel (v2).  A whole-row build of this kernel for them was
+// measured in round 3 (query in LDS, 8 or 16 rows per wave and step): 4.28 TB/s at d = 1024 and 3.77 TB/s at d = 1536 against v2's
+// 4.69 / 4.86 TB/s (Q = 10000, R = 1024, N = 1.5M; gpurun_out/r03e_refine.log, profiles/r03_refine_long_rows.txt).  With four lanes
+// per row -- the reference's four accumulator chains cannot be split further -- a 3 KB row costs one lane 192 dependent pair
+// steps while half the wave idles (8 rows x 3 KB fill the same 24 KB slot as 16 x 1.5 KB), and a 16-row slot no longer leaves
+// room for six waves per CU; v2's lane-per-row layout keeps all 64 lanes busy on 64 rows.
 }  // namespace nvdbhip

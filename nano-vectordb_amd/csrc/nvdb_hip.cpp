@@ -28,6 +28,7 @@
 #include "kernels_exact.h"
 #include "kernels_exact_mfma.h"
 #include "kernels_filter.h"
+#include "kernels_filter_i8s.h"
 #include "kernels_largek.h"
 #include "kernels_refine.h"
 #include "nvdb_common.h"
@@ -73,6 +74,7 @@ struct nvdb_hip_ctx {
   int64_t opt_i8_wide = 1;
   int64_t opt_i8_waves8 = 0;                       // ... on 8 waves of 32 queries (two per SIMD) instead of 4 of 64: 1 % slower (profiles/r02_i8_waves8_ab.txt), off
   int64_t opt_i8_defer = 0;                        // pipelined build: 1 = second stage inside the tile loop (deferred v_dot4 slots), 0 = log the first stage's survivors, finish them after the stream
+  int64_t opt_i8_mfma16 = 1;                       // int8 batches > 128, d = 512 / 768: the pipelined build on v_mfma_i32_16x16x64_i8 (kernels_filter_i8s.h): +7.3 % (profiles/r03_i8_mfma16_ab.txt); 0 (developer build): the 32x32x32 build
   int64_t opt_i8_pipe = 1;                         // int8 batches > 128: software-pipelined build (stage-1 test in the shadow of the other row block's MFMAs)
   int64_t opt_waves8 = 1;                          // d=768: 8-wave workgroups (two waves per SIMD, 32 queries each) for the fp16 m16 kernel: +2.3 % (0: four waves x 64 queries)
   void* pinned = nullptr;                           // pinned host staging of small calls: status words, results, queries
@@ -432,8 +434,14 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
                               uint32_t cap) {
   constexpr int MBK = DIM <= 384 ? 4 : 2;                 // 16-row blocks per tile of the m16 build: 64-row tiles up to d=384
   constexpr size_t lds = static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * DIM * 2 * (DIM <= 384 ? 2 : 1);
-  const bool m16 = (NB == 2) && c->opt_mfma16;
-  const void* fn = m16 ? reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM, 6, false, false, 0, MBK>) : reinterpret_cast<const void*>(filter_f16_kernel<DIM, NB>);
+#ifdef NVDB_HIP_DEV
+  const bool m16 = (NB == 2) && c->opt_mfma16;           // developer build: option mfma16 = 0 selects the 32x32x16 build for batches > 128 (A/B only)
+  constexpr bool HAS_WIDE32 = true;
+#else
+  const bool m16 = (NB == 2);
+  constexpr bool HAS_WIDE32 = (NB == 1);                 // the product instantiates filter_f16_kernel for batches <= 128 (and as the bootstrap build) only
+#endif
+  const void* fn = m16 ? reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM, 6, false, false, 0, MBK>) : reinterpret_cast<const void*>(filter_f16_kernel<DIM, HAS_WIDE32 ? NB : 1>);
   if (!c->lds_attr_set.count(fn)) {
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     c->lds_attr_set.insert(fn);
@@ -482,7 +490,7 @@ nvdb_status launch_filter_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, u
                                                        static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, 16 * MBK), nullptr, 0u, 0u);
     }
   }
-  else
+  else if constexpr (HAS_WIDE32)
     hipExtLaunchKernelGGL((filter_f16_kernel<DIM, NB>), dim3(nwg), dim3(256), lds, s, c->launch_e0, c->launch_e1, 0, filter_rows_f16(c), row_lo, row_hi,
                                                      static_cast<const _Float16*>(c->q16.p), nq, QT, static_cast<const float*>(c->thr.p),
                                                      static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),
@@ -566,6 +574,7 @@ nvdb_status launch_filter_k_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo,
   return NVDB_OK;
 }
 
+#ifdef NVDB_HIP_DEV   // the two-plane int8 kernel (option i8_wide = 0): the reference build the two-stage kernels are compared with
 template <int DIM>
 nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT,
                                  uint32_t nq_pad, uint32_t cap) {
@@ -604,6 +613,8 @@ nvdb_status launch_filter_i8_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
+
+#endif  // NVDB_HIP_DEV
 
 // threshold bootstrap on the matrix cores (fp16): best (score,row) of every 32-row tile of rows [0,n0) per query
 // -> cand[q][tile]; the caller then runs select(mode 2) to turn the k-th largest tile maximum into thr[q].
@@ -662,25 +673,55 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
   }
-  const bool pipe = (NB == 2) && c->opt_i8_pipe;
+#define NVDB_I8S_LAUNCH(SYNCV, PROG, MASK, LEAD)                                                                                  \
+  {                                                                                                                             \
+    if constexpr (DIM >= 512) {                                                                                                 \
+      constexpr size_t ldss = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + 4 * 256);                                         \
+      const void* fn = reinterpret_cast<const void*>(filter_i8s_kernel<DIM, SYNCV>);                                            \
+      if (!c->lds_attr_set.count(fn)) {                                                                                         \
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldss)));                 \
+        c->lds_attr_set.insert(fn);                                                                                             \
+      }                                                                                                                         \
+      hipExtLaunchKernelGGL((filter_i8s_kernel<DIM, SYNCV>), dim3(nwg), dim3(256), ldss, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
+          static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),   \
+          static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
+    }                                                                                                                           \
+  }
+#ifdef NVDB_HIP_DEV
+  const bool pipe = (NB == 2) && c->opt_i8_pipe;         // developer build: i8_pipe = 0 runs filter_i8w_kernel at 64 queries per wave, i8_waves8 = 1 the 8-wave pipelined build
   const bool w8 = pipe && c->opt_i8_waves8;
+  constexpr bool HAS_I8W = true, HAS_I8P32 = true;
+#else
+  const bool pipe = (NB == 2);
+  constexpr bool w8 = false;
+  constexpr bool HAS_I8W = (NB == 1);                    // the product runs filter_i8w_kernel for batches <= 128 only
+  constexpr bool HAS_I8P32 = (DIM < 512);                // ... and the 32x32x32 logged build only where the 16x16x64 build does not exist
+#endif
   const bool defer = c->opt_i8_defer != 0 || c->i8_scales_signed;
+  const bool s16 = pipe && !w8 && !defer && c->opt_i8_mfma16 && DIM >= 512;
   const uint32_t smask = static_cast<uint32_t>(c->opt_sync_every - 1), slead = static_cast<uint32_t>(c->opt_sync_lead);
   if (sync) {
     uint32_t* prog = nullptr;
     if ((st = next_prog_region(c, s, nwg, &prog))) return st;
-    if (w8) NVDB_I8P_LAUNCH(true, prog, smask, slead, 8, true)              // the 8-wave variant exists with the in-loop second stage only
+    if (s16) NVDB_I8S_LAUNCH(true, prog, smask, slead)
+#ifdef NVDB_HIP_DEV
+    else if (w8) NVDB_I8P_LAUNCH(true, prog, smask, slead, 8, true)              // the 8-wave variant exists with the in-loop second stage only
+#endif
     else if (pipe && defer) NVDB_I8P_LAUNCH(true, prog, smask, slead, 4, true)
-    else if (pipe) NVDB_I8P_LAUNCH(true, prog, smask, slead, 4, false)
-    else NVDB_I8W_LAUNCH(true, prog, smask, slead)
+    else if (pipe) { if constexpr (HAS_I8P32) NVDB_I8P_LAUNCH(true, prog, smask, slead, 4, false) }
+    else if constexpr (HAS_I8W) NVDB_I8W_LAUNCH(true, prog, smask, slead)
   } else {
-    if (w8) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 8, true)
+    if (s16) NVDB_I8S_LAUNCH(false, nullptr, 0u, 0u)
+#ifdef NVDB_HIP_DEV
+    else if (w8) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 8, true)
+#endif
     else if (pipe && defer) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 4, true)
-    else if (pipe) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 4, false)
-    else NVDB_I8W_LAUNCH(false, nullptr, 0u, 0u)
+    else if (pipe) { if constexpr (HAS_I8P32) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 4, false) }
+    else if constexpr (HAS_I8W) NVDB_I8W_LAUNCH(false, nullptr, 0u, 0u)
   }
 #undef NVDB_I8W_LAUNCH
 #undef NVDB_I8P_LAUNCH
+#undef NVDB_I8S_LAUNCH
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
@@ -777,9 +818,11 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
       NVDB_I8W_DIM(768); NVDB_I8W_DIM(512); NVDB_I8W_DIM(256);
 #undef NVDB_I8W_DIM
     }
+#ifdef NVDB_HIP_DEV
     if (c->fdim == 768) return launch_filter_i8_dim<768>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->fdim == 512) return launch_filter_i8_dim<512>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->fdim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+#endif
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 filter kernel: unsupported dim");
   }
   if (c->fdim == 2048) return launch_filter_k2_dim<2048>(c, s, row_lo, row_hi, nq, QT, cap);
@@ -1238,6 +1281,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "chunk0_rows") { if (value < 256) return fail(c, NVDB_ERR_INVALID, "chunk0_rows must be >= 256"); c->opt_chunk0 = value; }
   else if (k == "cand_cap") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "cand_cap out of range"); c->opt_cap = value; }
   else if (k == "time_kernels") { c->opt_time_kernels = value ? 1 : 0; }
+#ifdef NVDB_HIP_DEV
   else if (k == "mfma16") { c->opt_mfma16 = value ? 1 : 0; }
   else if (k == "sync_every") { if (value < 1 || (value & (value - 1))) return fail(c, NVDB_ERR_INVALID, "sync_every must be a power of two"); c->opt_sync_every = value; }
   else if (k == "sync_lead") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "sync_lead must be >= 1"); c->opt_sync_lead = value; }
@@ -1246,6 +1290,14 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }
   else if (k == "i8_pipe") { c->opt_i8_pipe = value ? 1 : 0; }
   else if (k == "i8_waves8") { c->opt_i8_waves8 = value ? 1 : 0; }
+  else if (k == "i8_mfma16") { c->opt_i8_mfma16 = value ? 1 : 0; }
+#else
+  // kernel variants that lost their A/B (32x32x16 fp16 build for batches > 128, two-plane int8 kernel, filter_i8w_kernel at 64 queries
+  // per wave, 8-wave int8 build, 32x32x32 int8 build at d >= 512) live in libnvdb_hip_dev.so only; the product accepts their default values
+  else if (k == "mfma16" || k == "i8_wide" || k == "i8_pipe" || k == "i8_mfma16") { if (!value) return fail(c, NVDB_ERR_UNSUPPORTED, k + " = 0 selects a developer-build kernel variant (libnvdb_hip_dev.so)"); }
+  else if (k == "i8_waves8") { if (value) return fail(c, NVDB_ERR_UNSUPPORTED, "i8_waves8 = 1 selects a developer-build kernel variant (libnvdb_hip_dev.so)"); }
+#endif
+
   else if (k == "i8_defer") { c->opt_i8_defer = value ? 1 : 0; }
   else if (k == "xcd_balance") { c->opt_xcd_balance = value ? 1 : 0; }
   else if (k == "i8_lo_bits") { if (value < 2 || value > 7) return fail(c, NVDB_ERR_INVALID, "i8_lo_bits must be in [2,7]"); c->opt_i8_lo_bits = value; }
@@ -1726,6 +1778,22 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
       case 13: NVDB_CLK_I8P(3, true) break;             // ... rare path, deferred values never consumed
       case 14: NVDB_CLK_I8P(4, true) break;             // ... rare path entered and left at once
       case 15: NVDB_CLK_I8P(5, true) break;             // ... production loop, cycles inside rare_path / consume_slots (wave 0 of every workgroup)
+#define NVDB_CLK_I8S(V)                                                                                                          \
+      {                                                                                                                          \
+        constexpr size_t ldss = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + 4 * 256);                                        \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_i8s_kernel<768, true, true, 6, V>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldss))); \
+        for (uint32_t r = 0; r < burst; ++r) {                                                                                   \
+          HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, prog_bytes, c->stream));                                                     \
+          filter_i8s_kernel<768, true, true, 6, V><<<nwg, 256, ldss, c->stream>>>(                                               \
+              filter_rows_i8(c), filter_scales_i8(c), 0, n_al, qhi, qlo, nq, QT, static_cast<const float*>(c->thr.p),            \
+              static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<const float*>(c->qdelta.p), \
+              static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap, I8W_TILE_ROWS), static_cast<uint32_t*>(c->prog.p),    \
+              static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead), static_cast<uint32_t*>(c->misc.p) + 4); \
+        }                                                                                                                        \
+      }
+      case 30: NVDB_CLK_I8S(0) break;                // the 16x16x64 build (kernels_filter_i8s.h), stamped
+      case 31: NVDB_CLK_I8S(1) break;                // ... its structure alone: no test, nothing logged
+      case 32: NVDB_CLK_I8S(2) break;                // ... test, nothing logged
       case 20: NVDB_CLK_I8P(0, false) break;         // the default build (first-stage survivors logged, finished after the stream), stamped
       case 22: NVDB_CLK_I8P(2, false) break;         // ... test, nothing logged
       case 24: NVDB_CLK_I8P(4, false) break;         // ... logging entered and left at once
@@ -1743,6 +1811,7 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
   }
 #undef NVDB_CLK_I8
 #undef NVDB_CLK_I8P
+#undef NVDB_CLK_I8S
   std::vector<uint64_t> stamps(static_cast<size_t>(nwg) * 2);
   HIPCHK(c, hipMemcpy(stamps.data(), static_cast<const char*>(c->prog.p) + prog_bytes, stamp_bytes, hipMemcpyDeviceToHost));
   std::vector<float> ghz;
@@ -1889,23 +1958,6 @@ static nvdb_status launch_refine(nvdb_hip_ctx* c, hipStream_t s, const float* dq
     }
     if (c->dim == 768) NVDB_REFINE3(768) else if (c->dim == 512) NVDB_REFINE3(512) else if (c->dim == 384) NVDB_REFINE3(384) else NVDB_REFINE3(256)
 #undef NVDB_REFINE3
-    HIPCHK(c, hipGetLastError());
-    return NVDB_OK;
-  }
-  // v3 for long fp16 rows (2 KB / 3 KB): query in LDS, 8 whole rows per wave and step
-  if (c->opt_refine_v2 >= 2 && c->dtype == NVDB_DTYPE_F16 && (c->dim == 1024 || c->dim == 1536)) {
-#define NVDB_REFINE3L(D)                                                                                                       \
-    {                                                                                                                          \
-      constexpr size_t lds = static_cast<size_t>(REFINE3_WAVES) * REFINE3L_ROWS * (D * 2 + 16) + D * 4;                        \
-      const void* fn = reinterpret_cast<const void*>(refine_l2_rows_long_kernel<D>);                                           \
-      if (!c->lds_attr_set.count(fn)) {                                                                                        \
-        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                 \
-        c->lds_attr_set.insert(fn);                                                                                            \
-      }                                                                                                                        \
-      refine_l2_rows_long_kernel<D><<<Q, 64 * REFINE3_WAVES, lds, s>>>(c->rows, c->n, dq, dc, R, K, doi, dod);                  \
-    }
-    if (c->dim == 1024) NVDB_REFINE3L(1024) else NVDB_REFINE3L(1536)
-#undef NVDB_REFINE3L
     HIPCHK(c, hipGetLastError());
     return NVDB_OK;
   }

@@ -356,7 +356,8 @@ class DeviceGroup:
 
     def __init__(self, devices):
         self.lib = load_library()
-        _share_rccl_with_torch()
+        if self.lib.nvdb_hip_device_count() > 0:             # (no GPU: creation fails below without ever needing RCCL)
+            _share_rccl_with_torch()
         arr = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
         st = self.lib.nvdb_hip_group_create(arr, len(devices), C.byref(h))

@@ -62,7 +62,7 @@ def test_no_kernel_uses_scratch_or_spills(codegen):
     # SGPRs parked in VGPR lanes cost nothing in memory; only the exact fp32 kernels at 8 queries per group do it
     parked = {k for k, v in by_name.items() if v["sspill"]}
     # i8p: the 4-slot deferred queue is uniform state; i8w (the A/B alternative, not the default): the XCD-balance stamp and label
-    assert all(k.startswith(("scan_exact_kernel<", "filter_i8p_kernel<", "filter_i8w_kernel<")) for k in parked), parked
+    assert all(k.startswith(("scan_exact_kernel<", "filter_i8p_kernel<", "filter_i8w_kernel<", "filter_i8s_kernel<768, true, true")) for k in parked), parked   # (i8s: its stamped developer build only)
 
 
 def test_register_budgets_of_the_production_kernels(codegen):
@@ -82,6 +82,12 @@ def test_register_budgets_of_the_production_kernels(codegen):
     assert k["agpr"] >= 192 and k["occ"] == 1, k                      # ... with the in-loop second stage (option i8_defer)
     k = _find(by_name, "filter_i8p_kernel<768, true, false, 6, 0, 8, true>")
     assert k["vgpr"] <= 128 and k["agpr"] <= 128 and k["agpr"] >= 96 and k["occ"] == 2, k   # its 8-wave variant (option i8_waves8): 32 queries per wave, two waves per SIMD
+    k = _find(by_name, "filter_i8s_kernel<768, true, false, 6, 0>")
+    assert k["agpr"] >= 192 and k["occ"] == 1 and k["sspill"] == 0, k  # the product's int8 batch-1024 kernel (16x16x64 MFMA): hi plane of 64 queries in AGPRs
+    # exact fp32-order scores on the fp32 matrix cores: 16 queries x 768 floats stationary (192 registers) + a tile of raw rows in flight
+    for name in ("scan_exact_mfma_kernel<2, 768>", "scan_exact_mfma_kernel<1, 768>", "scan_exact_mfma_kernel<3, 768>", "scores_exact_mfma_kernel<2, 768>"):
+        k = _find(by_name, name)
+        assert k["vgpr"] + k["agpr"] <= 512 and k["occ"] == 1, (name, k)
     k = _find(by_name, "filter_f16_kernelILi768ELi1ELi0ELi6E")
     assert k["agpr"] >= 192, k
     # refine v3: two workgroups of three waves per CU -> at most 256 registers per lane
@@ -115,6 +121,14 @@ def test_rendezvous_registers_and_hand_placed_instructions(codegen):
     assert body.count("global_load_lds_dwordx4") >= 6 and "s_nop 15" in body
     loop = body[body.index("s_barrier"):]
     assert loop.count("v_accvgpr_read") <= 8, loop.count("v_accvgpr_read")
+    # exact MFMA scan, fp16 rows: 192 fp32 MFMAs per tile, every refill load behind a COUNTED wait (one tile of prefetch
+    # distance: vmcnt(23) per step, never a drain inside the tile loop)
+    k = _find(by_name, "scan_exact_mfma_kernel<2, 768>")
+    body = _body(asm, k["mangled"])
+    assert body.count("v_mfma_f32_16x16x4_f32") == 192 and body.count("s_waitcnt vmcnt(23)") >= 24, (body.count("v_mfma_f32_16x16x4_f32"), body.count("s_waitcnt vmcnt(23)"))
+    k = _find(by_name, "filter_i8s_kernel<768, true, false, 6, 0>")
+    body = _body(asm, k["mangled"])
+    assert body.count("v_mfma_i32_16x16x64_i8") == 192 and "v_mfma_i32_32x32x32_i8" not in body
     # refine v3: q - half as ONE v_fma_mix_f32 per element (hipcc folds the C++ form back into cvt + sub)
     k = _find(by_name, "refine_l2_rows_kernel<768>")
     body = _body(asm, k["mangled"])

@@ -26,6 +26,16 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(scope="module")
+def ctx_dev():
+    """A context of libnvdb_hip_dev.so: the same ABI plus the kernel variants that lost their A/B (32x32x16 fp16 build for
+    batches > 128, two-plane int8 kernel, filter_i8w_kernel at 64 queries per wave, 8-wave and 32x32x32 int8 builds); the
+    product library compiles none of them and rejects the options that select them."""
+    c = nvdb_amd.HipContext(0, dev=True)
+    yield c
+    c.close()
+
+
 def _as_dtype(oracle, base32, tag):
     if tag == "f32":
         return base32, po.DT_F32, None
@@ -158,8 +168,9 @@ def test_filter_path_fp32_corpus_via_fp16_shadow(ctx, oracle, golden, nq):
     assert np.array_equal(gi, golden["main768_f32_st_ids"]) and np.array_equal(gs.view(np.uint32), golden["main768_f32_st_scores"])
 
 
-def test_filter_path_mfma16_variant_matches_default(ctx, oracle):
-    """The 16x16x32-MFMA build of the filter kernel must give the same bits as the 32x32x16 build."""
+def test_filter_path_mfma16_variant_matches_default(ctx_dev, oracle):
+    """The 16x16x32-MFMA build of the filter kernel (the product's) must give the same bits as the 32x32x16 build (developer library)."""
+    ctx = ctx_dev
     n, d, nq, k = 90000 + 5, 768, 300, 10
     ctx.generate_corpus(SEED + 50, n, d, nvdb_amd.DT_F16)
     base, _ = nvdb_amd.synth_corpus(SEED + 50, 0, n, d, nvdb_amd.DT_F16)
@@ -171,7 +182,7 @@ def test_filter_path_mfma16_variant_matches_default(ctx, oracle):
         res[m16] = ctx.search_batch(queries, k)
         st = ctx.stats()
         assert st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
-    ctx.set_option("mfma16", 0)
+    ctx.set_option("mfma16", 1)
     ctx.set_option("path", 0)
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
     _check_against_oracle(oracle, base, po.DT_F16, None, queries, res[1][0], res[1][1], k, "mfma16")
@@ -199,10 +210,11 @@ def test_filter_path_int8_matches_oracle(ctx, oracle, nq, k, d):
 
 
 @pytest.mark.parametrize("nq,k,d", [(300, 10, 768), (1024, 10, 768), (130, 64, 512), (200, 5, 256), (64, 10, 768), (1, 10, 768)])
-def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx, oracle, nq, k, d):
-    """int8 corpora run the two-stage kernel: hi plane always, lo plane only for tiles whose hi-plane value
+def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx_dev, oracle, nq, k, d):
+    """(developer library: it holds the builds the product's kernel is compared with)  int8 corpora run the two-stage kernel: hi plane always, lo plane only for tiles whose hi-plane value
     could reach the threshold (64 queries per wave for batches > 128, 32 below).  It must log exactly the survivors of the two-plane kernel, so ids, score
     bits and the number of rescored candidates are identical; both match the CPU int8 path."""
+    ctx = ctx_dev
     n = 200000 + 9
     ctx.generate_corpus(SEED + 80, n, d, nvdb_amd.DT_I8)
     base, scales = nvdb_amd.synth_corpus(SEED + 80, 0, n, d, nvdb_amd.DT_I8)
@@ -215,13 +227,15 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx, oracle, nq, k, d):
     res, stats = {}, {}
     # 0: two-plane kernel; 1: two-stage, software-pipelined build for batches > 128, first-stage survivors logged and finished
     # after the stream (the default); 2: two-stage, filter_i8w_kernel; 3: the pipelined build with the in-loop second stage
-    # (deferred v_dot4 slots); 4: the same on 8 waves of 32 queries
-    variants = ((0, 1, 0, 0), (1, 1, 0, 0), (1, 0, 0, 0), (1, 1, 0, 1), (1, 1, 1, 1))
-    for var, (wide, pipe, w8, defer) in enumerate(variants):
+    # (deferred v_dot4 slots); 4: the same on 8 waves of 32 queries; 5: the product's default: the logged build on
+    # v_mfma_i32_16x16x64_i8 (d >= 512; d = 256 keeps the 32x32x32 build)
+    variants = ((0, 1, 0, 0, 0), (1, 1, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 0, 1, 0), (1, 1, 1, 1, 0), (1, 1, 0, 0, 1))
+    for var, (wide, pipe, w8, defer, m16) in enumerate(variants):
         ctx.set_option("i8_wide", wide)
         ctx.set_option("i8_pipe", pipe)
         ctx.set_option("i8_waves8", w8)
         ctx.set_option("i8_defer", defer)
+        ctx.set_option("i8_mfma16", m16)
         res[var] = ctx.search_batch(queries, k)
         stats[var] = ctx.stats()
         assert stats[var]["path"] == 2 and stats[var]["bound_violations"] == 0 and stats[var]["overflow_queries"] == 0, stats[var]
@@ -229,6 +243,7 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx, oracle, nq, k, d):
     ctx.set_option("i8_pipe", 1)
     ctx.set_option("i8_waves8", 0)
     ctx.set_option("i8_defer", 0)
+    ctx.set_option("i8_mfma16", 1)
     ctx.set_option("path", 0)
     for var in range(1, len(variants)):
         assert np.array_equal(res[0][0], res[var][0]) and np.array_equal(res[0][1].view(np.uint32), res[var][1].view(np.uint32)), var
@@ -1220,6 +1235,14 @@ def test_exact_mfma_pruned_by_thresholds_and_small_row_ranges(oracle):
     c.close()
     assert np.array_equal(ids, ei) and np.array_equal(sc.view(np.uint32), es.view(np.uint32))
     _check_against_oracle(oracle, base, po.DT_F16, None, queries[:6], ids[:6], sc[:6], k, "exact-mfma k=64")
+
+
+def test_product_library_rejects_developer_variants(ctx):
+    for key, val in (("mfma16", 0), ("i8_wide", 0), ("i8_pipe", 0), ("i8_waves8", 1), ("i8_mfma16", 0)):
+        with pytest.raises(nvdb_amd.NvdbError) as e:
+            ctx.set_option(key, val)
+        assert e.value.status == 3 and "developer-build" in str(e.value)
+        ctx.set_option(key, 1 - val)                         # the default value is accepted
 
 
 def test_randomised_cross_check():

@@ -9,14 +9,15 @@ import numpy as np, torch, nvdb_amd
 n, d, B, K = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, 768, 1024, 10
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
-ctx = nvdb_amd.HipContext(0)
+ctx = nvdb_amd.HipContext(0, dev=True)     # the developer library holds the variants
 ctx.generate_corpus(20240613, n, d, nvdb_amd.DT_I8)
 q = torch.from_numpy(nvdb_amd.synth_rows_f32(20240614, 0, 4 * B, d)).to(dev)
 oi = torch.empty((B, K), dtype=torch.int64, device=dev); os_ = torch.empty((B, K), dtype=torch.float32, device=dev)
 ref = None
 for rnd in range(3):
-    for pipe, w8, defer in ((1, 0, 0), (1, 0, 1), (0, 0, 0)):
+    for pipe, w8, defer, m16 in ((1, 0, 0, 0), (1, 0, 0, 1), (1, 0, 1, 0), (1, 0, 0, 1), (1, 0, 0, 0)):
         ctx.set_option("i8_pipe", pipe)
+        ctx.set_option("i8_mfma16", m16)
         ctx.set_option("i8_waves8", w8)
         ctx.set_option("i8_defer", defer)
         strm = torch.cuda.current_stream().cuda_stream
@@ -28,5 +29,5 @@ for rnd in range(3):
         got = (oi.cpu().numpy().copy(), os_.cpu().numpy().copy())
         if ref is None: ref = got
         same = np.array_equal(ref[0], got[0]) and np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32))
-        print(f"round {rnd} i8_pipe={pipe} i8_waves8={w8} i8_defer={defer}: {el * 1e3:.3f} ms per pass = {B / el:.0f} queries/s = {2.0 * B * n * d / el / 1e12:.0f} TOP/s algorithmic; "
+        print(f"round {rnd} i8_pipe={pipe} i8_waves8={w8} i8_defer={defer} i8_mfma16={m16}: {el * 1e3:.3f} ms per pass = {B / el:.0f} queries/s = {2.0 * B * n * d / el / 1e12:.0f} TOP/s algorithmic; "
               f"stage1 {st['i8_stage1_tiles']} stage2 blocks {st['i8_stage2_blocks']} candidates {st['candidates']}; same results as the first run: {same}", flush=True)

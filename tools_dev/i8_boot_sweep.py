@@ -15,8 +15,10 @@ q = torch.from_numpy(nvdb_amd.synth_rows_f32(20240614, 0, 4 * B, d)).to(dev)
 oi = torch.empty((B, K), dtype=torch.int64, device=dev); os_ = torch.empty((B, K), dtype=torch.float32, device=dev)
 ref = None
 growths = (5, 6, 8) if dt == nvdb_amd.DT_I8 else ((0, 4, 6, 12, 16) if B > 128 else (0, 16, 32, 64))
+if len(sys.argv) > 4: growths = tuple(int(x) for x in sys.argv[4].split(','))
+tile_list = [int(x) for x in sys.argv[5].split(',')] if len(sys.argv) > 5 else None
 for rnd in range(2):
-    for lb, tiles in (((7, 0), (7, 256), (7, 384), (7, 512), (7, 768), (7, 1024), (7, 1536)) if dt == nvdb_amd.DT_I8 else ((7, 0), (7, 256), (7, 1024), (7, 2048))):
+    for lb, tiles in ([(7, t_) for t_ in tile_list] if tile_list else ((7, 0), (7, 256), (7, 384), (7, 512), (7, 768), (7, 1024), (7, 1536)) if dt == nvdb_amd.DT_I8 else ((7, 0), (7, 256), (7, 1024), (7, 2048))):
         for growth in growths:
             if dt == nvdb_amd.DT_I8: ctx.set_option("i8_lo_bits", lb)
             ctx.set_option("boot_tiles", tiles)

@@ -17,8 +17,8 @@ q = nvdb_amd.synth_rows_f32(20240614, 0, nq, 768)
 ctx.set_option("path", 2); ctx.search_batch(q, 10)
 st = ctx.stats()
 print(f"search: {st}", flush=True)
-names = {20: "pipelined build, first-stage survivors logged and finished after the stream (the default)", 22: "default build, test only (nothing logged)", 24: "default build, logging entered and left at once", 10: "pipelined build with the in-loop second stage (i8_defer=1)", 11: "pipelined structure alone (no test, no rare path)", 12: "pipelined, test in the MFMA shadow, rare path never taken", 13: "pipelined, rare path without consuming the deferred values", 14: "pipelined, rare path entered and left at once", 0: "filter_i8w_kernel loop", 1: "no stage 2 (lo plane never multiplied)", 2: "no stage-1 test either (stream + hi-plane MFMAs)", 3: "the same without the per-tile barrier"}
-for var in (20, 24, 22, 11, 10, 20, 24, 22):
+names = {30: "16x16x64 build (kernels_filter_i8s.h)", 31: "16x16x64 build, structure alone (no test, nothing logged)", 32: "16x16x64 build, test only", 20: "pipelined build, first-stage survivors logged and finished after the stream (the default)", 22: "default build, test only (nothing logged)", 24: "default build, logging entered and left at once", 10: "pipelined build with the in-loop second stage (i8_defer=1)", 11: "pipelined structure alone (no test, no rare path)", 12: "pipelined, test in the MFMA shadow, rare path never taken", 13: "pipelined, rare path without consuming the deferred values", 14: "pipelined, rare path entered and left at once", 0: "filter_i8w_kernel loop", 1: "no stage 2 (lo plane never multiplied)", 2: "no stage-1 test either (stream + hi-plane MFMAs)", 3: "the same without the per-tile barrier"}
+for var in ([int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (20, 24, 22, 11, 10, 20, 24, 22)):
     out = (C.c_float * 8)()
     rc = lib.nvdb_hip_debug_clock_i8(ctx.h, var, nq, secs, out)
     assert rc == 0, lib.nvdb_hip_last_error(ctx.h)
@@ -30,6 +30,7 @@ for var in (20, 24, 22, 11, 10, 20, 24, 22):
           f"in-kernel clock median {med:.3f} GHz (min {lo:.3f}, max {hi:.3f}); MFMA pipe busy {busy:.3f}; cycles per tile {3072 / busy:.0f}; "
           f"rare-path entries {out[4]:.0f}, lo-plane MFMA blocks {out[5]:.0f} per launch ({n // 64 * 16 * 2} wave-halves)", flush=True)
 # where a rare-path entry's time goes: cycles wave 0 of every workgroup spent inside rare_path / consume_slots (variant 15)
+if len(sys.argv) > 3: sys.exit(0)
 out = (C.c_float * 8)()
 rc = lib.nvdb_hip_debug_clock_i8(ctx.h, 15, nq, secs, out)
 assert rc == 0, lib.nvdb_hip_last_error(ctx.h)
