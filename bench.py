@@ -253,7 +253,7 @@ def cli_legs(nvdb_amd, args, base_p, N, tmpdir):
     """The CLI surface the north star names, timed at BASELINE configs in fresh child processes (nothing of this
     process' GPU state is shared with them):
       * `nvdb_bench <base> <4096 queries> 10 gpu 0 1 1024` on the 10M-row vecbin of the cpu_baseline leg (configs[1]):
-        one-time upload, then 4 batches of 1024 through nvdb::FlatIndexHIP -> C ABI host entry (PCIe-inclusive);
+        one-time upload, then 16 batches of 1024 through nvdb::FlatIndexHIP -> C ABI host entry (PCIe-inclusive);
       * `nvdb_cuda_refine_eval <base> <10000 queries> 10` with REFINE_K=1024 on the first 2.9M rows (configs[4]):
         synthetic candidates, CPU refine (OpenMP) beside the drop-in nvdb::cuda_l2_topk_batch call.
     Output lines are the reference's (apps/nvdb_bench.cpp:379-425; apps/nvdb_ivf_eval.cpp:572-576, 743-779)."""
@@ -268,8 +268,8 @@ def cli_legs(nvdb_amd, args, base_p, N, tmpdir):
     env = dict(os.environ, OMP_NUM_THREADS=str(host_cpu_info()["threads_used"]))
     try:
         if args.dtype == "f16" or args.dtype == "i8":
-            nq_cli = 4 * args.batch
-            po.write_raw12(q_p, nvdb_amd.synth_rows_f32(SEED + 1, 0, nq_cli, D))        # the bench's own four query batches
+            nq_cli = 16 * args.batch                                                     # 16 batches: a fresh process needs a few passes to settle (XCD shares, clocks)
+            po.write_raw12(q_p, np.tile(nvdb_amd.synth_rows_f32(SEED + 1, 0, 4 * args.batch, D), (4, 1)))    # the bench's own four query batches, four times
             t0 = time.perf_counter()
             txt = subprocess.run([os.path.join(bin_dir, "nvdb_bench"), base_p, q_p, str(K), "gpu", "0", "1", str(args.batch)],
                                  env=env, capture_output=True, text=True, timeout=600, check=True).stdout
@@ -555,7 +555,7 @@ def main():
         sec = kt["ms"] * 1e-3
         ach = kt["flops"] / sec / 1e12
         peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_I8_TOPS
-        kname = (("filter_f16_m16_kernel<768> (8 waves x 32 queries)" if B > 128 else "filter_f16_kernel<768,1>") if args.dtype == "f16" else ("filter_i8p_kernel<768> (software-pipelined two-stage build)" if B > 128 else "filter_i8w_kernel<768,1>"))
+        kname = (("filter_f16_m16_kernel<768> (8 waves x 32 queries)" if B > 128 else "filter_f16_kernel<768,1>") if args.dtype == "f16" else ("filter_i8s_kernel<768> (two-stage build on v_mfma_i32_16x16x64_i8)" if B > 128 else "filter_i8w_kernel<768,1>"))
         gbps = kt["bytes"] / sec / 1e9
         # ridge point: intensity = 2*B*dim flop per row / row bytes  vs  peak flop / peak bytes
         hbm_bound = (2.0 * B * D / bpr) < (peak * 1e12 / (PEAK_HBM_GBPS * 1e9))
@@ -647,6 +647,18 @@ def main():
             extras["sweep"] = {"note": "whole-pass wall time per point (bootstrap, selects and rescore included), 4 timed passes each; "
                                        "fractions against 8 TB/s and the dense MFMA peak of the dtype",
                                "fp16": sweep_points(ctx, D * 2, PEAK_F16_TFLOPS)}
+            # (1c) the exact fp32-order path (fallback / any-k / this script's own parity check): 64 queries against the whole corpus
+            ctx.set_option("path", 1)
+            ex = {}
+            for mf in (1, 0):
+                ctx.set_option("exact_mfma", mf)
+                el_ = timed_passes(ctx, 64, reps=2)
+                ex["fp32_mfma" if mf else "valu"] = {"ms_per_pass": el_ * 1e3, "TFLOPs": 2.0 * 64 * N * D / el_ / 1e12}
+            ctx.set_option("exact_mfma", 1)
+            ctx.set_option("path", args.path)
+            extras["exact_path_batch64"] = {"workload": f"exact fp32-order scan (path 1), fp16 corpus N={N} d={D}, 64 queries", **ex,
+                                            "kernels": "scan_exact_mfma_kernel (v_mfma_f32_16x16x4_f32, eight accumulator tiles = the reference's eight fma chains) vs scan_exact_kernel (VALU)",
+                                            "fp32_matrix_peak_TFLOPs": 157.3}
             # (2) BASELINE configs[2]: int8(+scale), same shape
             c8 = nvdb_amd.HipContext(local_rank)
             c8.generate_corpus(SEED, N, D, nvdb_amd.DT_I8)

@@ -69,7 +69,7 @@ typedef struct nvdb_hip_scan_stats {
   uint64_t candidates;         /* (query,row) pairs that reached the exact rescore                */
   uint32_t overflow_queries;   /* queries whose candidate list overflowed (re-run on path 1)      */
   uint32_t bound_violations;   /* |filter - exact| > bound seen by the rescore (must be 0)        */
-  float    filter_kernel_ms;   /* sum of hipEvent times of the dominant kernel's launches         */
+  float    filter_kernel_ms;   /* sum of hipEvent times of the dominant kernel's launches (host API with a timing struct and option "time_launches" = 1; else 0) */
   float    other_kernel_ms;    /* prep + select + rescore + merge                                  */
   uint32_t i8_stage1_tiles;    /* int8 two-stage kernel: (wave, tile) pairs that went past the hi-plane quick test */
   uint32_t i8_stage2_blocks;   /* ... 32-query blocks for which the lo plane was multiplied after all           */
@@ -208,10 +208,14 @@ nvdb_status nvdb_hip_group_search_batch(nvdb_hip_group* group, const float* quer
                                         nvdb_hip_group_stats* stats);
 
 /* Tunables (defaults are what bench.py measures; the table with meanings is in INTEGRATION.md section 4b):
- * "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "chunk_growth", "cand_cap", "min_filter_batch", "mfma_boot",
- * "mfma16", "waves8", "sibling_sync", "sync_every", "sync_lead", "tile_permute", "f32_shadow" (set before the upload),
- * "i8_wide", "i8_pipe", "i8_defer", "i8_waves8", "i8_lo_bits", "boot_tiles", "xcd_balance", "rescore8", "refine_v2", "refine_pinned" (reference CUDA_PINNED: pinned host staging in nvdb_hip_refine_l2_topk), "largek_budget_mb" (HBM for the any-k path's score matrix), "time_kernels" (1: start / stop events attached to every launch of the dominant
- * kernel).  Unknown key -> NVDB_ERR_INVALID. */
+ * "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "chunk_growth", "cand_cap", "min_filter_batch", "mfma_boot", "waves8",
+ * "sibling_sync", "sync_every", "sync_lead", "tile_permute", "f32_shadow" (set before the upload), "exact_mfma" (exact scores on the fp32
+ * matrix cores), "i8_defer", "i8_lo_bits", "boot_tiles", "xcd_balance", "rescore8", "refine_v2", "refine_pinned" (reference CUDA_PINNED:
+ * pinned host staging in nvdb_hip_refine_l2_topk), "largek_budget_mb" (HBM for the any-k path's score matrix), "time_kernels" (1: start /
+ * stop events attached to every launch of the dominant kernel, read by nvdb_hip_collect_kernel_times), "time_launches" (the same for one host-API
+ * call with a timing struct -> stats.filter_kernel_ms).  "mfma16", "i8_wide", "i8_pipe", "i8_waves8", "i8_mfma16" select kernel
+ * variants that exist in libnvdb_hip_dev.so only: the product accepts their default values (1, 1, 1, 0, 1) and returns
+ * NVDB_ERR_UNSUPPORTED for the others.  Unknown key -> NVDB_ERR_INVALID. */
 nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* ctx, const char* key, int64_t value);
 
 /* With "time_kernels" = 1: sum of the hipEvent durations of the dominant (filter) kernel's launches

@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels_exact.h"
+#include "kernels_filter.h"        // glds16_v, NVDB_LPTR: direct-to-LDS loads issued from inline asm
 
 namespace nvdbhip {
 
@@ -328,6 +329,245 @@ __global__ __launch_bounds__(256, 1) void scores_exact_mfma_kernel(const void* _
       else {
 #pragma unroll
         for (int v = 0; v < 4; ++v) if (row0 + v < n) o[v] = s[v];
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// The same tiles with the rows STAGED THROUGH LDS once per workgroup (full groups of 64 queries: four waves = four blocks of 16
+// queries over the same 16-row tile).
+//
+// The register-direct kernels above let every wave fetch its own copy of a tile in 64-byte-per-row pieces: four times the
+// L2 -> CU traffic in half-line requests, and 60-80 TFLOP/s (profiles/r03_exact_mfma_bench.txt).  Here the four waves bring a tile
+// in together as 1-KB direct-to-LDS pieces (whole 128-byte lines, each row byte crosses the L2 -> CU path once), three stages
+// deep (two for fp32 rows of 768: 48 KB stages), and read their A operand back with ds_read_b128 / b64.
+//   LDS image: chunk c (16 bytes) of row r at position c ^ (r & 15) of the row -- applied on the SOURCE address of the
+//   direct-to-LDS load, whose LDS side is linear.  Lane (x15, kq) reads chunk 4t + kq (fp16), chunks 2(4t + kq), +1 (fp32) or
+//   half kq & 1 of chunk 2t + kq / 2 (int8) of row x15: 16 distinct 16-byte bank slots per lane group in every case.
+//   One s_barrier per tile; loads counted by hand (s_waitcnt vmcnt) because they are invisible to the compiler, which is also why
+//   the int8 row scales come in through LDS: an ordinary load's compiler-made wait would drain the prefetch.
+// Results are bit-identical to the register-direct kernels and to the VALU kernels (same chains, same order).
+// ================================================================================================
+template <int DT, int DIM> constexpr bool exact_lds_shape() {
+  return (16 * DIM * exact_bpe<DT>()) % 4096 == 0 && (DIM * exact_bpe<DT>()) % 256 == 0;    // whole pieces per wave; XOR stays inside a row
+}
+template <int DT, int DIM> constexpr int exact_lds_stages() { return 3 * 16 * DIM * exact_bpe<DT>() + 3 * 256 + 33 * 1024 <= 160 * 1024 ? 3 : 2; }
+template <int DT, int DIM> constexpr int exact_lds_bytes() { return exact_lds_stages<DT, DIM>() * (16 * DIM * exact_bpe<DT>() + 256); }
+
+// 4 bytes per lane HBM -> LDS (the int8 row scales): LDS address = lds_off + lane * 4
+__device__ __forceinline__ void glds4_v(const void* gptr, uint32_t lds_off) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds_off) : "memory");
+}
+
+// SCORES = false: the scan (top-k lists, contract of scan_exact_kernel); true: the score matrix (contract of scores_exact_kernel).
+// grid = (row splits, nq / 64): ONLY full groups of 64 queries (the caller sends the rest to the register-direct kernels).
+template <int DT, int DIM, bool SCORES>
+__global__ __launch_bounds__(256, 1) void exact_mfma_lds_kernel(
+    const void* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
+    const float* __restrict__ q32, uint32_t nq, uint32_t k, const float* __restrict__ thr,
+    Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t* __restrict__ overflow,
+    float* __restrict__ out, uint64_t ld) {
+  static_assert(DIM % 32 == 0 && DIM <= 768 && exact_lds_shape<DT, DIM>(), "whole MFMA K-steps; whole 1-KB pieces per wave");
+  constexpr int BPE = exact_bpe<DT>(), T = DIM / 32, ROW_BYTES = DIM * BPE, CHUNKS_PER_ROW = ROW_BYTES / 16;
+  constexpr int DATA_BYTES = 16 * ROW_BYTES, STAGE_BYTES = DATA_BYTES + 256;       // + four 64-byte copies of the tile's row scales (int8)
+  constexpr int NSTAGE = exact_lds_stages<DT, DIM>(), PIECES = DATA_BYTES / 1024, PPW = PIECES / 4;
+  constexpr int LPT = PPW + (DT == DT_I8 ? 1 : 0);                                 // loads per wave and tile
+  constexpr int RING = 4;                                                          // K-steps of LDS reads in flight
+  static_assert(T % PPW == 0 || PPW % T == 0, "pieces spread evenly over the K-steps");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float l_s[SCORES ? 1 : 4][SCORES ? 1 : EXACT_MFMA_QB][64];
+  __shared__ uint32_t l_id[SCORES ? 1 : 4][SCORES ? 1 : EXACT_MFMA_QB][64];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x15 = lane & 15, kq = lane >> 4;
+  const uint32_t qg0 = blockIdx.y * 64u;
+  const uint32_t qi = qg0 + wave * EXACT_MFMA_QB + x15;          // < nq: full groups only
+
+  float bq[T][8];
+  exact_load_bq<DIM>(q32, qi, nq, kq, bq);
+  // consume the fragments HERE: hipcc otherwise defers its wait for these loads to their first use inside the tile loop, and that
+  // s_waitcnt vmcnt(0) would also wait for the direct-to-LDS prefetches it cannot see -- once per tile
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(bq[t][j]));
+  const float gthr = (!SCORES && thr != nullptr) ? thr[qi] : NEG_INF;
+  asm volatile("" ::"v"(gthr));
+
+  const uint32_t P = gridDim.x, p = blockIdx.x;
+  const uint32_t tiles = (row_hi - row_lo + EXACT_MFMA_ROWS - 1) / EXACT_MFMA_ROWS;
+  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * p / P), t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * (p + 1) / P);
+  if (t_lo >= t_hi) return;
+
+  // loader: piece i of this wave = linear 16-byte slots [(wave * PPW + i) * 64, +64) of the stage; slot L = row L / CHUNKS_PER_ROW,
+  // position L % CHUNKS_PER_ROW, filled from source chunk position ^ (row & 15) of that row (clamped into the row range)
+  uint32_t piece_row[PPW], piece_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const uint32_t L = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
+    const uint32_t r = L / CHUNKS_PER_ROW, cpos = L % CHUNKS_PER_ROW;
+    piece_row[i] = r;
+    piece_off[i] = (cpos ^ (r & 15u)) << 4;
+  }
+  const char* gbase = static_cast<const char*>(rows);
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
+  auto issue_piece = [&](uint32_t tile, int i) {
+    const uint32_t tl = tile < t_hi ? tile : t_hi - 1;           // beyond my range: the last tile again (never read)
+    uint32_t r = row_lo + tl * EXACT_MFMA_ROWS + piece_row[i];
+    r = r < row_hi ? r : row_hi - 1;
+    glds16_v(gbase + static_cast<uint64_t>(r) * ROW_BYTES + piece_off[i], lds_base + (tl % NSTAGE) * STAGE_BYTES + (wave * PPW + i) * 1024);
+  };
+  auto issue_scales = [&](uint32_t tile) {
+    if constexpr (DT == DT_I8) {
+      const uint32_t tl = tile < t_hi ? tile : t_hi - 1;
+      uint32_t r = row_lo + tl * EXACT_MFMA_ROWS + static_cast<uint32_t>(x15);
+      r = r < row_hi ? r : row_hi - 1;
+      if (lane < 16) glds4_v(scales + r, lds_base + (tl % NSTAGE) * STAGE_BYTES + DATA_BYTES + wave * 64);
+    }
+  };
+  // NOTE: a stage is chosen by the TILE index (tile % NSTAGE), so prefetches beyond t_hi land in the stage of the last tile --
+  // only after that tile has been consumed?  No: they are issued while it is being read.  Keep them out: see `have` below.
+  auto issue_tile = [&](uint32_t tile) {
+    if (tile < t_hi) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) issue_piece(tile, i);
+      issue_scales(tile);
+    }
+  };
+
+  // this lane's read offsets inside a stage
+  const uint32_t row_off = static_cast<uint32_t>(x15) * ROW_BYTES;
+  auto read_step = [&](const char* stage, int t) -> ExactRaw<DT> {
+    ExactRaw<DT> r;
+    if constexpr (DT == DT_F16) {
+      const uint32_t c = 4u * t + kq;
+      r.v = *reinterpret_cast<const uint4*>(stage + row_off + ((c ^ static_cast<uint32_t>(x15)) << 4));
+    } else if constexpr (DT == DT_F32) {
+      const uint32_t c = 2u * (4u * t + kq);
+      r.a = *reinterpret_cast<const float4*>(stage + row_off + ((c ^ static_cast<uint32_t>(x15)) << 4));
+      r.b = *reinterpret_cast<const float4*>(stage + row_off + (((c + 1u) ^ static_cast<uint32_t>(x15)) << 4));
+    } else {
+      const uint32_t c = 2u * t + (static_cast<uint32_t>(kq) >> 1);
+      r.v = *reinterpret_cast<const uint2*>(stage + row_off + ((c ^ static_cast<uint32_t>(x15)) << 4) + 8u * (kq & 1));
+    }
+    return r;
+  };
+
+  float thr_s = NEG_INF;
+  uint32_t thr_id = 0xFFFFFFFFu, my_cnt = 0;
+
+  // prologue: the first NSTAGE - 1 tiles
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) issue_tile(t_lo + st);
+  // tiles whose loads were actually issued count in vmcnt; near the end fewer are outstanding, and a too-generous count would
+  // let a stage be read before it has landed: wait for everything once the prefetch has run dry
+  for (uint32_t tile = t_lo; tile < t_hi; ++tile) {
+    if (tile + NSTAGE - 1 <= t_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NSTAGE - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // tile `tile` has landed for every wave; nobody still reads the stage of tile - 1
+    const char* stage = smem + (tile % NSTAGE) * STAGE_BYTES;
+    const uint32_t nxt = tile + NSTAGE - 1;
+    ExactRaw<DT> ring[RING];
+#pragma unroll
+    for (int t = 0; t < RING - 1; ++t) ring[t] = read_step(stage, t);
+    floatx4_t acc[8];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + RING - 1 < T) ring[(t + RING - 1) % RING] = read_step(stage, t + RING - 1);
+      float x[8];
+      exact_raw_to_f32<DT>(ring[t % RING], x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (t == 0) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], bq[0][j], floatx4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], bq[t][j], acc[j], 0, 0, 0);
+      }
+      // the next tile-but-one's pieces, spread over the K-steps
+      if (nxt < t_hi) {
+        if constexpr (T >= PPW) { if (t % (T / PPW) == 0) issue_piece(nxt, t / (T / PPW)); }
+        else {
+#pragma unroll
+          for (int i = 0; i < PPW / T; ++i) issue_piece(nxt, t * (PPW / T) + i);
+        }
+        if (t == 1) issue_scales(nxt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float s[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float s0 = acc[0][v] + acc[4][v], s1 = acc[1][v] + acc[5][v], s2 = acc[2][v] + acc[6][v], s3 = acc[3][v] + acc[7][v];
+      s[v] = (s0 + s1) + (s2 + s3);
+    }
+    const uint32_t row0 = row_lo + tile * EXACT_MFMA_ROWS + 4u * static_cast<uint32_t>(kq);
+    if constexpr (DT == DT_I8) {
+      const float4 sc = *reinterpret_cast<const float4*>(stage + DATA_BYTES + wave * 64 + 16 * kq);
+      s[0] *= sc.x; s[1] *= sc.y; s[2] *= sc.z; s[3] *= sc.w;                      // simd_dot.cpp:198
+    }
+    if constexpr (SCORES) {
+      float* o = out + static_cast<uint64_t>(qi) * ld + row0;
+      if (row0 + 3 < row_hi) *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
+      else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) if (row0 + v < row_hi) o[v] = s[v];
+      }
+    } else {
+      bool pass[4];
+      bool any = false;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const uint32_t row = row0 + v;
+        pass[v] = row < row_hi && s[v] >= gthr && (my_cnt < k || better(s[v], row, thr_s, thr_id));
+        any = any || pass[v];
+      }
+      if (!__ballot(any)) continue;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        unsigned long long m = __ballot(pass[v]);
+        while (m) {
+          const int L = __builtin_ctzll(m);
+          m &= m - 1;
+          const uint32_t g = static_cast<uint32_t>(L) & 15u;
+          const float cs = readlane_f(s[v], L);
+          const uint32_t cid = row_lo + tile * EXACT_MFMA_ROWS + 4u * (static_cast<uint32_t>(L) >> 4) + v;
+          const uint32_t c = readlane_u(my_cnt, static_cast<int>(g));
+          const float ts = readlane_f(thr_s, static_cast<int>(g));
+          const uint32_t tid = readlane_u(thr_id, static_cast<int>(g));
+          if (!(c < k || better(cs, cid, ts, tid))) continue;
+          float es = l_s[SCORES ? 0 : wave][SCORES ? 0 : g][lane];
+          uint32_t eid = l_id[SCORES ? 0 : wave][SCORES ? 0 : g][lane];
+          const bool ahead = static_cast<uint32_t>(lane) < c && better(es, eid, cs, cid);
+          const uint32_t pos = static_cast<uint32_t>(__builtin_popcountll(__ballot(ahead)));
+          const float up_s = __shfl_up(es, 1);
+          const uint32_t up_id = __shfl_up(eid, 1);
+          if (static_cast<uint32_t>(lane) > pos) { es = up_s; eid = up_id; }
+          else if (static_cast<uint32_t>(lane) == pos) { es = cs; eid = cid; }
+          const uint32_t c2 = c < k ? c + 1 : k;
+          if (static_cast<uint32_t>(lane) < c2) { l_s[SCORES ? 0 : wave][SCORES ? 0 : g][lane] = es; l_id[SCORES ? 0 : wave][SCORES ? 0 : g][lane] = eid; }
+          const float nts = readlane_f(es, static_cast<int>(k) - 1);
+          const uint32_t ntid = readlane_u(eid, static_cast<int>(k) - 1);
+          if (static_cast<uint32_t>(x15) == g) {
+            my_cnt = c2;
+            if (c2 == k) { thr_s = nts; thr_id = ntid; }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (!SCORES) {
+    for (uint32_t g = 0; g < EXACT_MFMA_QB; ++g) {
+      const uint32_t q = qg0 + wave * EXACT_MFMA_QB + g;
+      const uint32_t c = readlane_u(my_cnt, static_cast<int>(g));
+      if (c == 0) continue;
+      uint32_t slot0 = 0;
+      if (lane == 0) slot0 = atomicAdd(&cnt[q], c);
+      slot0 = readlane_u(slot0, 0);
+      if (static_cast<uint32_t>(lane) < c) {
+        const uint32_t slot = slot0 + lane;
+        if (slot < cap) cand[static_cast<uint64_t>(q) * cap + slot] = Cand{l_s[SCORES ? 0 : wave][SCORES ? 0 : g][lane], l_id[SCORES ? 0 : wave][SCORES ? 0 : g][lane]};
+        else overflow[q] = 1u;
       }
     }
   }

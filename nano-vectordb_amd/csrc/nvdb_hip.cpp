@@ -86,6 +86,8 @@ struct nvdb_hip_ctx {
   hipEvent_t launch_e0 = nullptr, launch_e1 = nullptr;   // attached to the next filter launch (hipExtLaunchKernelGGL): its own start/stop timestamps, no extra packets
   std::vector<hipEvent_t> kl_pool;                  // recycled events of collected launches
   uint32_t prog_slot = 0;                          // next free region of the rendezvous counters (reset per search)
+  int64_t opt_time_launches = 0;                   // host API with a timing struct: 1 = also attach start / stop events to every filter launch (stats.filter_kernel_ms); costs ~0.1 ms per launch-rich pass
+  int64_t opt_exact_lds = 1;                       // exact MFMA kernels: full groups of 64 queries stage their row tiles through LDS once per workgroup (0: register-direct loads only)
   int64_t opt_exact_mfma = 1;                      // exact fp32-order scores on the fp32 matrix cores where the shape allows (kernels_exact_mfma.h); 0: VALU kernels only
   int64_t opt_rescore8 = 2;                        // rescore kernel: 0 lane per candidate, 1 eight lanes per candidate, 2 = 1 + rows staged through LDS
 
@@ -280,19 +282,47 @@ bool exact_mfma_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 38
 template <int DT>
 nvdb_status launch_scan_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, const float* q32,
                                    uint32_t nq, uint32_t k, const float* thr, uint32_t cap, uint32_t reserve) {
-  const uint32_t gy = (nq + 63) / 64;
-  const uint32_t last_blocks = (nq - (gy - 1) * 64 + 15) / 16;                    // 16-query blocks of the last (partial) group
-  const uint32_t nslice_max = last_blocks >= 3 ? 1u : (last_blocks == 2 ? 2u : 4u);
   const uint32_t tiles = (row_hi - row_lo + EXACT_MFMA_ROWS - 1) / EXACT_MFMA_ROWS;
+  Cand* cand = static_cast<Cand*>(c->cand.p);
+  uint32_t* cnt = static_cast<uint32_t*>(c->cnt.p);
+  uint32_t* ovf = static_cast<uint32_t*>(c->overflow.p);
+  uint32_t q0 = 0;                                  // queries [0, q0) are served by the LDS-staged kernel (full groups of 64)
+  bool lds_done = false;
+#define NVDB_SCAN_LDS(D)                                                                                                           \
+  if constexpr (exact_lds_shape<DT, D>()) {                                                                                        \
+    if (c->opt_exact_lds && nq >= 64 && c->dim == D) {                                                                             \
+      const uint32_t gy = nq / 64;                                                                                                 \
+      const uint32_t pmax = (cap > reserve + k) ? (cap - reserve) / k : 1;                                                         \
+      uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);                                  \
+      P = std::max<uint32_t>(1, std::min(std::min(P, std::max<uint32_t>(1, tiles / 8)), pmax));                                    \
+      const void* fn = reinterpret_cast<const void*>(exact_mfma_lds_kernel<DT, D, false>);                                         \
+      if (!c->lds_attr_set.count(fn)) {                                                                                            \
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, exact_lds_bytes<DT, D>()));                  \
+        c->lds_attr_set.insert(fn);                                                                                                \
+      }                                                                                                                            \
+      exact_mfma_lds_kernel<DT, D, false><<<dim3(P, gy), 256, exact_lds_bytes<DT, D>(), s>>>(c->rows, c->scales, row_lo, row_hi, q32, gy * 64, k, thr, \
+                                                                                             cand, cnt, cap, ovf, nullptr, 0);     \
+      HIPCHK(c, hipGetLastError());                                                                                                \
+      q0 = gy * 64; lds_done = true;                                                                                               \
+    }                                                                                                                              \
+  }
+  NVDB_SCAN_LDS(768) NVDB_SCAN_LDS(512) NVDB_SCAN_LDS(384) NVDB_SCAN_LDS(256) NVDB_SCAN_LDS(128)
+#undef NVDB_SCAN_LDS
+  (void)lds_done;
+  if (q0 >= nq) return NVDB_OK;
+  // the rest (fewer than 64 queries, or everything when the LDS-staged build does not take the shape): register-direct kernel
+  const uint32_t nr = nq - q0;
+  const uint32_t gy = (nr + 63) / 64;
+  const uint32_t last_blocks = (nr - (gy - 1) * 64 + 15) / 16;                    // 16-query blocks of the last (partial) group
+  const uint32_t nslice_max = last_blocks >= 3 ? 1u : (last_blocks == 2 ? 2u : 4u);
   const uint32_t pmax = (cap > reserve + k * nslice_max) ? (cap - reserve) / (k * nslice_max) : 1;
   uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);   // ~2 workgroups per CU in all (one resident at a time)
   P = std::min(P, std::max<uint32_t>(1, tiles / 8));                                           // >= 8 tiles each
   P = std::max<uint32_t>(1, std::min(P, pmax));
   const dim3 grid(P, gy);
-  Cand* cand = static_cast<Cand*>(c->cand.p);
-  uint32_t* cnt = static_cast<uint32_t*>(c->cnt.p);
-  uint32_t* ovf = static_cast<uint32_t*>(c->overflow.p);
-#define NVDB_SCAN_MFMA(D) scan_exact_mfma_kernel<DT, D><<<grid, 256, 0, s>>>(c->rows, c->scales, row_lo, row_hi, q32, nq, k, thr, cand, cnt, cap, ovf)
+  const float* qr = q32 + static_cast<size_t>(q0) * c->dim;
+  const float* thr_r = thr ? thr + q0 : nullptr;
+#define NVDB_SCAN_MFMA(D) scan_exact_mfma_kernel<DT, D><<<grid, 256, 0, s>>>(c->rows, c->scales, row_lo, row_hi, qr, nr, k, thr_r, cand + static_cast<size_t>(q0) * cap, cnt + q0, cap, ovf + q0)
   switch (c->dim) {
     case 768: NVDB_SCAN_MFMA(768); break;
     case 512: NVDB_SCAN_MFMA(512); break;
@@ -854,11 +884,38 @@ nvdb_status launch_scores_exact_qg(nvdb_hip_ctx* c, hipStream_t s, const float* 
 // the same score matrix from the fp32 matrix cores (kernels_exact_mfma.h)
 nvdb_status launch_scores_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uint32_t nq, float* out, uint64_t ld) {
   const uint32_t n = static_cast<uint32_t>(c->n);
-  const uint32_t gy = (nq + 63) / 64, tiles = (n + EXACT_MFMA_ROWS - 1) / EXACT_MFMA_ROWS;
+  const uint32_t tiles = (n + EXACT_MFMA_ROWS - 1) / EXACT_MFMA_ROWS;
+  uint32_t q0 = 0;
+#define NVDB_SC_LDS(DT, D)                                                                                                          \
+  if constexpr (exact_lds_shape<DT, D>()) {                                                                                        \
+    if (c->opt_exact_lds && nq >= 64 && c->dim == D) {                                                                             \
+      const uint32_t gy = nq / 64;                                                                                                 \
+      uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);                                  \
+      P = std::max<uint32_t>(1, std::min(P, std::max<uint32_t>(1, tiles / 8)));                                                    \
+      const void* fn = reinterpret_cast<const void*>(exact_mfma_lds_kernel<DT, D, true>);                                          \
+      if (!c->lds_attr_set.count(fn)) {                                                                                            \
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, exact_lds_bytes<DT, D>()));                  \
+        c->lds_attr_set.insert(fn);                                                                                                \
+      }                                                                                                                            \
+      exact_mfma_lds_kernel<DT, D, true><<<dim3(P, gy), 256, exact_lds_bytes<DT, D>(), s>>>(c->rows, c->scales, 0u, n, q32, gy * 64, 0u, nullptr, \
+                                                                                            nullptr, nullptr, 0u, nullptr, out, ld);   \
+      HIPCHK(c, hipGetLastError());                                                                                                \
+      q0 = gy * 64;                                                                                                                \
+    }                                                                                                                              \
+  }
+#define NVDB_SC_LDS_DT(DT) NVDB_SC_LDS(DT, 768) NVDB_SC_LDS(DT, 512) NVDB_SC_LDS(DT, 384) NVDB_SC_LDS(DT, 256) NVDB_SC_LDS(DT, 128)
+  if (c->dtype == NVDB_DTYPE_F32) { NVDB_SC_LDS_DT(DT_F32) } else if (c->dtype == NVDB_DTYPE_F16) { NVDB_SC_LDS_DT(DT_F16) } else { NVDB_SC_LDS_DT(DT_I8) }
+#undef NVDB_SC_LDS_DT
+#undef NVDB_SC_LDS
+  if (q0 >= nq) return NVDB_OK;
+  const uint32_t nr = nq - q0;
+  const uint32_t gy = (nr + 63) / 64;
   uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);
   P = std::max<uint32_t>(1, std::min(P, tiles / 8));
   const dim3 grid(P, gy);
-#define NVDB_SC_MFMA(DT, D) scores_exact_mfma_kernel<DT, D><<<grid, 256, 0, s>>>(c->rows, c->scales, n, q32, nq, out, ld)
+  const float* qr = q32 + static_cast<size_t>(q0) * c->dim;
+  float* outr = out + static_cast<size_t>(q0) * ld;
+#define NVDB_SC_MFMA(DT, D) scores_exact_mfma_kernel<DT, D><<<grid, 256, 0, s>>>(c->rows, c->scales, n, qr, nr, outr, ld)
 #define NVDB_SC_MFMA_DT(DT)                                                                                       \
   switch (c->dim) {                                                                                              \
     case 768: NVDB_SC_MFMA(DT, 768); break;                                                                      \
@@ -1281,12 +1338,12 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "chunk0_rows") { if (value < 256) return fail(c, NVDB_ERR_INVALID, "chunk0_rows must be >= 256"); c->opt_chunk0 = value; }
   else if (k == "cand_cap") { if (value < 0 || value > SELECT_MAX_CAP) return fail(c, NVDB_ERR_INVALID, "cand_cap out of range"); c->opt_cap = value; }
   else if (k == "time_kernels") { c->opt_time_kernels = value ? 1 : 0; }
-#ifdef NVDB_HIP_DEV
-  else if (k == "mfma16") { c->opt_mfma16 = value ? 1 : 0; }
   else if (k == "sync_every") { if (value < 1 || (value & (value - 1))) return fail(c, NVDB_ERR_INVALID, "sync_every must be a power of two"); c->opt_sync_every = value; }
   else if (k == "sync_lead") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "sync_lead must be >= 1"); c->opt_sync_lead = value; }
   else if (k == "sibling_sync") { c->opt_sibling_sync = value ? 1 : 0; }
   else if (k == "f32_shadow") { c->opt_f32_shadow = value ? 1 : 0; }
+#ifdef NVDB_HIP_DEV
+  else if (k == "mfma16") { c->opt_mfma16 = value ? 1 : 0; }
   else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }
   else if (k == "i8_pipe") { c->opt_i8_pipe = value ? 1 : 0; }
   else if (k == "i8_waves8") { c->opt_i8_waves8 = value ? 1 : 0; }
@@ -1307,6 +1364,8 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
 #endif
   else if (k == "waves8") { c->opt_waves8 = value ? 1 : 0; }
   else if (k == "exact_mfma") { c->opt_exact_mfma = value ? 1 : 0; }
+  else if (k == "exact_lds") { c->opt_exact_lds = value ? 1 : 0; }
+  else if (k == "time_launches") { c->opt_time_launches = value ? 1 : 0; }
   else if (k == "tile_permute") { c->opt_tile_permute = value ? 1 : 0; }
   else if (k == "rescore8") { c->opt_rescore8 = value < 0 ? 0 : (value > 2 ? 2 : value); }
   else if (k == "mfma_boot") { c->opt_mfma_boot = value ? 1 : 0; }
@@ -1429,7 +1488,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     const float* dq = static_cast<const float*>(c->q32.p);
     uint64_t* oi = static_cast<uint64_t*>(c->out_ids.p);
     float* os = static_cast<float*>(c->out_scores.p);
-    if ((st = search_core(c, s, dq, nq, k, oi, os, 0, timing != nullptr, 0, false))) return st;
+    if ((st = search_core(c, s, dq, nq, k, oi, os, 0, timing != nullptr && c->opt_time_launches, 0, false))) return st;
     HIPCHK(c, hipEventRecord(e2, s));
     auto fetch = [&]() -> nvdb_status {
       HIPCHK(c, hipMemcpyAsync(pin_status, c->misc.p, 32, hipMemcpyDeviceToHost, s));
@@ -1494,7 +1553,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     const float* dq = static_cast<const float*>(c->q32.p) + static_cast<size_t>(q0) * c->dim;
     uint64_t* oi = static_cast<uint64_t*>(c->out_ids.p) + static_cast<size_t>(q0) * k;
     float* os = static_cast<float*>(c->out_scores.p) + static_cast<size_t>(q0) * k;
-    if ((st = search_core(c, s, dq, b, k, oi, os, 0, timing != nullptr, 0, false))) return st;
+    if ((st = search_core(c, s, dq, b, k, oi, os, 0, timing != nullptr && c->opt_time_launches, 0, false))) return st;
     HIPCHK(c, hipStreamSynchronize(s));
     nvdb_hip_scan_stats part{};
     nvdb_status chk = search_check_impl(c, &part, true);

@@ -88,15 +88,14 @@ def _share_hip_runtime_with_torch():
 
 
 def _share_rccl_with_torch():
-    """Same for RCCL, which the device group binds with dlopen("librccl.so.1") on first use: PyTorch's bundled copy is
-    built against PyTorch's HIP runtime, so it is the one to have in the process (loaded lazily: only DeviceGroup needs it)."""
+    """Same for RCCL, which the device group binds with dlopen("librccl.so.1") on first use: PyTorch's bundled copy is built
+    against PyTorch's HIP runtime, so it is the one to have in the process.  PyTorch is IMPORTED for that (only DeviceGroup
+    does this): a bare dlopen of its librccl.so ahead of a later `import torch` changed the order in which the two tear their
+    statics down and aborted the interpreter at exit ("double free or corruption") once both had been used."""
     import importlib.util
-    spec = importlib.util.find_spec("torch")
-    if spec is None or not spec.submodule_search_locations:
+    if importlib.util.find_spec("torch") is None:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
-    if os.path.exists(cand):
-        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    import torch  # noqa: F401  (loads libamdhip64 / librccl in its own order)
 
 
 def _bind(L, dev):

@@ -1183,7 +1183,7 @@ def test_int8_corpus_with_a_huge_row_scale_takes_the_unbiased_build(oracle):
 
 
 @pytest.mark.parametrize("tag", ["f16", "f32", "i8"])
-@pytest.mark.parametrize("d,nq", [(768, 64), (768, 9), (768, 33), (384, 100), (128, 17), (512, 48), (256, 130)])
+@pytest.mark.parametrize("d,nq", [(768, 64), (768, 9), (768, 33), (384, 100), (128, 17), (512, 48), (256, 130), (128, 64), (768, 200)])
 def test_exact_scores_on_the_fp32_matrix_cores(oracle, tag, d, nq):
     """Path 1 with more than 8 queries on dims that are whole MFMA K-steps runs on v_mfma_f32_16x16x4_f32 (eight accumulator
     tiles = the reference's eight stride-8 fma chains, kernels_exact_mfma.h): ids and score BITS must equal the VALU kernels'
@@ -1204,20 +1204,49 @@ def test_exact_scores_on_the_fp32_matrix_cores(oracle, tag, d, nq):
     c.upload_corpus(base, dt, scales)
     c.set_option("path", 1)
     res = {}
-    for mf in (1, 0):
-        c.set_option("exact_mfma", mf)
+    for mf in (1, 2, 0):                                                 # 1: LDS-staged tiles for full groups of 64 queries, 2: register-direct loads only, 0: VALU kernels
+        c.set_option("exact_mfma", 1 if mf else 0)
+        c.set_option("exact_lds", 1 if mf == 1 else 0)
         res[mf] = c.search_batch(queries, k)
         assert c.stats()["path"] == 1
-    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))
+    for mf in (1, 2):
+        assert np.array_equal(res[mf][0], res[0][0]) and np.array_equal(res[mf][1].view(np.uint32), res[0][1].view(np.uint32)), mf
     sub = np.r_[0:8, nq - 1]
     _check_against_oracle(oracle, base, dt, scales, queries[sub], res[1][0][sub], res[1][1][sub], k, f"exact-mfma/{tag}/d{d}")
     # the any-k path's score matrix comes from the same tiles (k = 100 on 20K rows is off the filter path)
-    for mf in (1, 0):
-        c.set_option("exact_mfma", mf)
+    for mf in (1, 2, 0):
+        c.set_option("exact_mfma", 1 if mf else 0)
+        c.set_option("exact_lds", 1 if mf == 1 else 0)
         res[mf] = c.search_batch(queries, 100)
         assert c.stats()["path"] == 3
-    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))
+    for mf in (1, 2):
+        assert np.array_equal(res[mf][0], res[0][0]) and np.array_equal(res[mf][1].view(np.uint32), res[0][1].view(np.uint32)), mf
     c.close()
+
+
+def test_exact_mfma_lds_kernel_on_an_adopted_unpadded_corpus(oracle):
+    """The LDS-staged exact kernel brings tiles in with direct-to-LDS loads; on an ADOPTED corpus (the caller's buffer, no zero
+    padding behind the last row) a ragged last tile must be clamped into the row range, for rows and int8 scales alike."""
+    import torch
+    n, d, nq, k = 4096 + 5, 768, 128, 10                         # 5 rows in the last 16-row tile
+    dev = torch.device("cuda", 0)
+    for tag, dt in (("f16", nvdb_amd.DT_F16), ("i8", nvdb_amd.DT_I8), ("f32", nvdb_amd.DT_F32)):
+        base, scales = nvdb_amd.synth_corpus(SEED + 180, 0, n, d, dt)
+        queries = nvdb_amd.synth_rows_f32(SEED + 181, 0, nq, d)
+        queries[7] = (oracle.f16_to_f32(base[n - 2]) if tag == "f16" else (base[n - 2].astype(np.float32) * (scales[n - 2] if tag == "i8" else 1.0))).astype(np.float32)
+        view = base.view(np.int16) if tag == "f16" else base
+        t_rows = torch.from_numpy(view).to(dev).clone()           # exactly n rows: nothing behind them belongs to us
+        t_scales = torch.from_numpy(scales).to(dev).clone() if scales is not None else None
+        c = nvdb_amd.HipContext(0)
+        c.adopt_corpus(t_rows.data_ptr(), n, d, dt, t_scales.data_ptr() if t_scales is not None else None)
+        c.set_option("path", 1)
+        ids, sc = c.search_batch(queries, k)
+        c.set_option("exact_mfma", 0)
+        ei, es = c.search_batch(queries, k)
+        c.close()
+        assert np.array_equal(ids, ei) and np.array_equal(sc.view(np.uint32), es.view(np.uint32)), tag
+        assert ids[7, 0] == n - 2
+        _check_against_oracle(oracle, base, {"f16": po.DT_F16, "i8": po.DT_I8, "f32": po.DT_F32}[tag], scales, queries[5:9], ids[5:9], sc[5:9], k, f"exact-lds adopt/{tag}")
 
 
 def test_exact_mfma_pruned_by_thresholds_and_small_row_ranges(oracle):

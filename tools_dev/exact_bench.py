@@ -9,6 +9,7 @@ import numpy as np, torch, nvdb_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 K = 10
+MODES = ["valu", "mfma+lds", "mfma register-direct"]
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 strm = torch.cuda.current_stream().cuda_stream
@@ -21,8 +22,8 @@ for tag, dt in (("f16", nvdb_amd.DT_F16), ("i8", nvdb_amd.DT_I8), ("f32", nvdb_a
         oi = torch.empty((nq, K), dtype=torch.int64, device=dev); os_ = torch.empty((nq, K), dtype=torch.float32, device=dev)
         ref = None
         for rnd in range(2):
-            for mf in (1, 0):
-                ctx.set_option("exact_mfma", mf)
+            for mf in (1, 2, 0):
+                ctx.set_option("exact_mfma", 1 if mf else 0); ctx.set_option("exact_lds", 1 if mf == 1 else 0)
                 ctx.search_batch_dev(q.data_ptr(), nq, K, oi.data_ptr(), os_.data_ptr(), strm)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 reps = 3
@@ -33,6 +34,6 @@ for tag, dt in (("f16", nvdb_amd.DT_F16), ("i8", nvdb_amd.DT_I8), ("f32", nvdb_a
                 if ref is None: ref = got
                 same = np.array_equal(ref[0], got[0]) and np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32))
                 bpe = {"f16": 2, "i8": 1, "f32": 4}[tag]
-                print(f"{tag} n={n} d={d} nq={nq} round {rnd} exact_mfma={mf}: {el * 1e3:.3f} ms per pass = {2.0 * nq * n * d / el / 1e12:.1f} TFLOP/s, "
+                print(f"{tag} n={n} d={d} nq={nq} round {rnd} mode={MODES[mf]}: {el * 1e3:.3f} ms per pass = {2.0 * nq * n * d / el / 1e12:.1f} TFLOP/s, "
                       f"rows {n * d * bpe / el / 1e9:.0f} GB/s per query group pass; same results: {same}", flush=True)
     ctx.close()
