@@ -210,7 +210,7 @@ nvdb_status nvdb_hip_group_search_batch(nvdb_hip_group* group, const float* quer
 /* Tunables (defaults are what bench.py measures; the table with meanings is in INTEGRATION.md section 4b):
  * "path" (0 auto, 1 exact, 2 mfma-filter), "chunk0_rows", "chunk_growth", "cand_cap", "min_filter_batch", "mfma_boot", "waves8",
  * "sibling_sync", "sync_every", "sync_lead", "tile_permute", "f32_shadow" (set before the upload), "exact_mfma" (exact scores on the fp32
- * matrix cores), "i8_defer", "i8_lo_bits", "boot_tiles", "xcd_balance", "rescore8", "refine_v2", "refine_pinned" (reference CUDA_PINNED:
+ * matrix cores), "exact_lds", "i8_defer", "i8_lo_bits", "boot_tiles", "xcd_balance", "rescore8", "refine_v2", "refine_pinned" (reference CUDA_PINNED:
  * pinned host staging in nvdb_hip_refine_l2_topk), "largek_budget_mb" (HBM for the any-k path's score matrix), "time_kernels" (1: start /
  * stop events attached to every launch of the dominant kernel, read by nvdb_hip_collect_kernel_times), "time_launches" (the same for one host-API
  * call with a timing struct -> stats.filter_kernel_ms).  "mfma16", "i8_wide", "i8_pipe", "i8_waves8", "i8_mfma16" select kernel

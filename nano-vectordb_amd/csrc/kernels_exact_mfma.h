@@ -438,20 +438,24 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_lds_kernel(
     }
   };
 
-  // this lane's read offsets inside a stage
+  // this lane's read offsets inside a stage.  Chunk index c of step t XOR x15 splits into a part that depends on (t mod 2^m) only
+  // through an XOR of address bits and a part that is a plain multiple of 256 bytes, so a handful of base registers plus immediate
+  // offsets address every step (written out so that the compiler keeps it that way: 24 computed addresses spilled into AGPRs, and
+  // every v_accvgpr_read / v_add between two fp32 MFMAs costs ~10 cycles -- profiles/r03_mfma_f32_rate.txt)
   const uint32_t row_off = static_cast<uint32_t>(x15) * ROW_BYTES;
+  const uint32_t a_f16 = row_off + ((static_cast<uint32_t>(kq) ^ static_cast<uint32_t>(x15)) << 4);                       // chunk 4t + kq
+  const uint32_t a_f32_0 = row_off + (((2u * kq) ^ static_cast<uint32_t>(x15)) << 4);                                     // chunks 8t + 2kq, + 1
+  const uint32_t a_f32_1 = row_off + (((2u * kq + 1u) ^ static_cast<uint32_t>(x15)) << 4);
+  const uint32_t a_i8 = row_off + (((static_cast<uint32_t>(kq) >> 1) ^ static_cast<uint32_t>(x15)) << 4) + 8u * (kq & 1);  // half kq & 1 of chunk 2t + kq / 2
   auto read_step = [&](const char* stage, int t) -> ExactRaw<DT> {
     ExactRaw<DT> r;
     if constexpr (DT == DT_F16) {
-      const uint32_t c = 4u * t + kq;
-      r.v = *reinterpret_cast<const uint4*>(stage + row_off + ((c ^ static_cast<uint32_t>(x15)) << 4));
+      r.v = *reinterpret_cast<const uint4*>(stage + (a_f16 ^ ((t & 3) << 6)) + (t >> 2) * 256);
     } else if constexpr (DT == DT_F32) {
-      const uint32_t c = 2u * (4u * t + kq);
-      r.a = *reinterpret_cast<const float4*>(stage + row_off + ((c ^ static_cast<uint32_t>(x15)) << 4));
-      r.b = *reinterpret_cast<const float4*>(stage + row_off + (((c + 1u) ^ static_cast<uint32_t>(x15)) << 4));
+      r.a = *reinterpret_cast<const float4*>(stage + (a_f32_0 ^ ((t & 1) << 7)) + (t >> 1) * 256);
+      r.b = *reinterpret_cast<const float4*>(stage + (a_f32_1 ^ ((t & 1) << 7)) + (t >> 1) * 256);
     } else {
-      const uint32_t c = 2u * t + (static_cast<uint32_t>(kq) >> 1);
-      r.v = *reinterpret_cast<const uint2*>(stage + row_off + ((c ^ static_cast<uint32_t>(x15)) << 4) + 8u * (kq & 1));
+      r.v = *reinterpret_cast<const uint2*>(stage + (a_i8 ^ ((t & 7) << 5)) + (t >> 3) * 256);
     }
     return r;
   };

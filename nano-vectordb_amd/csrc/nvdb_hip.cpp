@@ -87,7 +87,7 @@ struct nvdb_hip_ctx {
   std::vector<hipEvent_t> kl_pool;                  // recycled events of collected launches
   uint32_t prog_slot = 0;                          // next free region of the rendezvous counters (reset per search)
   int64_t opt_time_launches = 0;                   // host API with a timing struct: 1 = also attach start / stop events to every filter launch (stats.filter_kernel_ms); costs ~0.1 ms per launch-rich pass
-  int64_t opt_exact_lds = 1;                       // exact MFMA kernels: full groups of 64 queries stage their row tiles through LDS once per workgroup (0: register-direct loads only)
+  int64_t opt_exact_lds = 1;                       // exact MFMA kernels: full groups of 64 queries stage their row tiles through LDS once per workgroup: 1 = for fp32 rows (101 vs 75 TFLOP/s; fp16 / int8 rows are faster register-direct: 86 vs 77), 2 = always, 0 = never
   int64_t opt_exact_mfma = 1;                      // exact fp32-order scores on the fp32 matrix cores where the shape allows (kernels_exact_mfma.h); 0: VALU kernels only
   int64_t opt_rescore8 = 2;                        // rescore kernel: 0 lane per candidate, 1 eight lanes per candidate, 2 = 1 + rows staged through LDS
 
@@ -290,7 +290,7 @@ nvdb_status launch_scan_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_
   bool lds_done = false;
 #define NVDB_SCAN_LDS(D)                                                                                                           \
   if constexpr (exact_lds_shape<DT, D>()) {                                                                                        \
-    if (c->opt_exact_lds && nq >= 64 && c->dim == D) {                                                                             \
+    if ((c->opt_exact_lds == 2 || (c->opt_exact_lds == 1 && DT == DT_F32)) && nq >= 64 && c->dim == D) {                          \
       const uint32_t gy = nq / 64;                                                                                                 \
       const uint32_t pmax = (cap > reserve + k) ? (cap - reserve) / k : 1;                                                         \
       uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);                                  \
@@ -888,7 +888,7 @@ nvdb_status launch_scores_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, const float
   uint32_t q0 = 0;
 #define NVDB_SC_LDS(DT, D)                                                                                                          \
   if constexpr (exact_lds_shape<DT, D>()) {                                                                                        \
-    if (c->opt_exact_lds && nq >= 64 && c->dim == D) {                                                                             \
+    if ((c->opt_exact_lds == 2 || (c->opt_exact_lds == 1 && DT == DT_F32)) && nq >= 64 && c->dim == D) {                          \
       const uint32_t gy = nq / 64;                                                                                                 \
       uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);                                  \
       P = std::max<uint32_t>(1, std::min(P, std::max<uint32_t>(1, tiles / 8)));                                                    \
@@ -1364,7 +1364,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
 #endif
   else if (k == "waves8") { c->opt_waves8 = value ? 1 : 0; }
   else if (k == "exact_mfma") { c->opt_exact_mfma = value ? 1 : 0; }
-  else if (k == "exact_lds") { c->opt_exact_lds = value ? 1 : 0; }
+  else if (k == "exact_lds") { if (value < 0 || value > 2) return fail(c, NVDB_ERR_INVALID, "exact_lds must be 0, 1 or 2"); c->opt_exact_lds = value; }
   else if (k == "time_launches") { c->opt_time_launches = value ? 1 : 0; }
   else if (k == "tile_permute") { c->opt_tile_permute = value ? 1 : 0; }
   else if (k == "rescore8") { c->opt_rescore8 = value < 0 ? 0 : (value > 2 ? 2 : value); }

@@ -1206,7 +1206,7 @@ def test_exact_scores_on_the_fp32_matrix_cores(oracle, tag, d, nq):
     res = {}
     for mf in (1, 2, 0):                                                 # 1: LDS-staged tiles for full groups of 64 queries, 2: register-direct loads only, 0: VALU kernels
         c.set_option("exact_mfma", 1 if mf else 0)
-        c.set_option("exact_lds", 1 if mf == 1 else 0)
+        c.set_option("exact_lds", 2 if mf == 1 else 0)
         res[mf] = c.search_batch(queries, k)
         assert c.stats()["path"] == 1
     for mf in (1, 2):
@@ -1216,7 +1216,7 @@ def test_exact_scores_on_the_fp32_matrix_cores(oracle, tag, d, nq):
     # the any-k path's score matrix comes from the same tiles (k = 100 on 20K rows is off the filter path)
     for mf in (1, 2, 0):
         c.set_option("exact_mfma", 1 if mf else 0)
-        c.set_option("exact_lds", 1 if mf == 1 else 0)
+        c.set_option("exact_lds", 2 if mf == 1 else 0)
         res[mf] = c.search_batch(queries, 100)
         assert c.stats()["path"] == 3
     for mf in (1, 2):
@@ -1240,6 +1240,7 @@ def test_exact_mfma_lds_kernel_on_an_adopted_unpadded_corpus(oracle):
         c = nvdb_amd.HipContext(0)
         c.adopt_corpus(t_rows.data_ptr(), n, d, dt, t_scales.data_ptr() if t_scales is not None else None)
         c.set_option("path", 1)
+        c.set_option("exact_lds", 2)                               # the LDS-staged build for every dtype (default: fp32 rows only)
         ids, sc = c.search_batch(queries, k)
         c.set_option("exact_mfma", 0)
         ei, es = c.search_batch(queries, k)

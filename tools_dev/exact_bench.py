@@ -23,7 +23,7 @@ for tag, dt in (("f16", nvdb_amd.DT_F16), ("i8", nvdb_amd.DT_I8), ("f32", nvdb_a
         ref = None
         for rnd in range(2):
             for mf in (1, 2, 0):
-                ctx.set_option("exact_mfma", 1 if mf else 0); ctx.set_option("exact_lds", 1 if mf == 1 else 0)
+                ctx.set_option("exact_mfma", 1 if mf else 0); ctx.set_option("exact_lds", 2 if mf == 1 else 0)
                 ctx.search_batch_dev(q.data_ptr(), nq, K, oi.data_ptr(), os_.data_ptr(), strm)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 reps = 3

@@ -10,7 +10,7 @@ ctx = nvdb_amd.HipContext(0)
 ctx.generate_corpus(20240613, n, 768, {"f16": nvdb_amd.DT_F16, "i8": nvdb_amd.DT_I8, "f32": nvdb_amd.DT_F32}[tag])
 ctx.set_option("path", 1)
 ctx.set_option("exact_mfma", 0 if mode == "valu" else 1)
-ctx.set_option("exact_lds", 1 if mode == "lds" else 0)
+ctx.set_option("exact_lds", 2 if mode == "lds" else 0)
 q = nvdb_amd.synth_rows_f32(20240614, 0, nq, 768)
 for _ in range(reps):
     ids, sc, t = ctx.search_batch(q, 10, want_timing=True)
