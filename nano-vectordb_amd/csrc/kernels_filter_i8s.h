@@ -26,20 +26,24 @@ typedef int intx4_t __attribute__((ext_vector_type(4)));
 #define NVDB_MFMA_I8S_ACC(acc, a, b) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 
 // VAR (STAMP builds only; wrong results): 1 = no test, no logging (structure alone), 2 = test, nothing logged.
-template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6, int VAR = 0>
-__global__ __launch_bounds__(256, 1) void filter_i8s_kernel(
+// WPB = 8: the same 256 queries per workgroup on 8 waves of 32 (two waves per SIMD, 128 + 128 registers each): a wave's LDS-DMA issue,
+// ring priming and barrier waits run beside its SIMD partner's MFMAs.
+template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6, int VAR = 0, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
     const signed char* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
     const signed char* __restrict__ qhi, const signed char* __restrict__ qlo, uint32_t nq, uint32_t QT,
     const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qinv,
     const float* __restrict__ qdelta, Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t* __restrict__ prog,
     uint32_t sync_mask, uint32_t sync_lead, uint32_t* __restrict__ stage_counts) {
-  constexpr int WPB = 4, NB = 4, MB = 2;                     // 4 waves x 4 blocks of 16 queries; 2 blocks of 32 rows per tile
+  static_assert(WPB == 4 || WPB == 8, "4 waves x 64 queries or 8 waves x 32 queries");
+  constexpr int NB = 16 / WPB, MB = 2;                       // blocks of 16 queries per wave; 2 blocks of 32 rows per tile
+  constexpr int NV = 8 * NB;                                 // values a lane tests per 32-row block
   constexpr int KS = DIM / 64;                               // k-steps of 64 bytes
   constexpr int ROW_BYTES = DIM;
   constexpr int TROWS = FILTER_ROWS * MB;
   constexpr int NSTAGE = 3;
   constexpr int DATA_BYTES = TROWS * ROW_BYTES;
-  constexpr int STAGE_BYTES = DATA_BYTES + 4 * 256;          // the tile + per-wave 256-byte copies of its 64 row scales
+  constexpr int STAGE_BYTES = DATA_BYTES + WPB * 256;        // the tile + per-wave 256-byte copies of its 64 row scales
   constexpr int PIECES = DATA_BYTES / 1024, PPW = PIECES / WPB;
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
   constexpr int NSLOT = 2 * NB * KS;                         // MFMAs (16 cycles each) per 32-row block
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8s_kernel(
   if (NT == 0) return;
 
   // stationary operand: hi plane of this wave's 4 blocks of 16 queries, all of K, in AGPRs
-  const uint32_t qbase = qt * 256u + wave * 64u;
+  const uint32_t qbase = qt * 256u + wave * (16u * NB);
   float4_t bq[NB * KS];
 #pragma unroll
   for (int f = 0; f < NB * KS; ++f) {
@@ -157,25 +161,25 @@ __global__ __launch_bounds__(256, 1) void filter_i8s_kernel(
     const int i = w - SW0;
     if (i >= 0 && i < 8) scc[set][i] = scv[set][i] * -8388608.f;
   };
-  // Stage-1 test of a block, one value per TWO MFMA slots (32 values over the 96 slots of a half at d = 768; an MFMA holds the
+  // Stage-1 test of a block, one value per TWO MFMA slots where they suffice (32 values over the 96 slots of a half at d = 768, 4 waves; an MFMA holds the
   // issue port for 8 of its 16 cycles): unit u = value v: (2^23 + H) * scale - 2^23 * scale = H * scale rounded once; odd v folds
   // the pair into the running maximum of its (query block, 16-row half).  Value v = 8 nb + 4 h + j.
-  float tm[32];
+  float tm[NV];
   constexpr int W0 = SW0 + 10;                     // the constants are ready (slots SW0 .. SW0 + 7)
-  constexpr int SPU = (NSLOT - W0 - 4) / 32 >= 2 ? 2 : 1;   // slots per unit
-  static_assert(W0 + 32 * SPU + 2 <= NSLOT, "the test ends before the half's last MFMA");
+  constexpr int SPU = (NSLOT - W0 - 4) / NV >= 2 ? 2 : 1;   // slots per unit
+  static_assert(W0 + NV * SPU + 2 <= NSLOT, "the test ends before the half's last MFMA");
   auto test_step = [&](const intx4_t (&a)[2][NB], const float (&sc)[8], const float (&sccs)[8], int w) {
     if constexpr (VAR == 1) return;
     const int rel = w - W0;
     if (rel < 0 || rel % SPU != 0) return;
     const int v = rel / SPU;
-    if (v < 32) {
+    if (v < NV) {
       const int nb = v >> 3, h = (v >> 2) & 1, j = v & 3;
       const int b0 = a[h][nb][j];
       tm[v] = __builtin_fmaf(__builtin_bit_cast(float, b0), sc[4 * h + j], sccs[4 * h + j]);
     }
     const int p = v - 1;                             // fold the pair completed one unit ago
-    if (p >= 0 && p < 32 && (p & 1)) mx[p >> 3][(p >> 2) & 1] = vmax3(mx[p >> 3][(p >> 2) & 1], tm[p - 1], tm[p]);
+    if (p >= 0 && p < NV && (p & 1)) mx[p >> 3][(p >> 2) & 1] = vmax3(mx[p >> 3][(p >> 2) & 1], tm[p - 1], tm[p]);
   };
   auto reset_max = [&]() {
 #pragma unroll
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8s_kernel(
     float m[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) m[nb] = vmax3(mx[nb][0], mx[nb][1], mx[nb][1]) - t1q[nb];
-    flagv = vmax3(vmax3(m[0], m[1], m[2]), m[3], m[3]);
+    flagv = NB == 4 ? vmax3(vmax3(m[0], m[1], m[NB / 2]), m[NB - 1], m[NB - 1]) : vmax3(m[0], m[NB - 1], m[NB - 1]);
   };
   auto any_flag = [&]() -> bool { return __builtin_amdgcn_ballot_w64(flagv >= 0.f) != 0; };
   // log the values of a tested block that pass the first stage -- row scale, row, query, H -- for the exact finish after the stream
@@ -220,7 +224,8 @@ __global__ __launch_bounds__(256, 1) void filter_i8s_kernel(
   // LDS-DMA issue of tile t + 2: half of a wave's pieces in each half of the tile, the first three in the bubble while the
   // A-fragment ring fills after the barrier
   constexpr int HP = PPW / 2, HP0 = HP < 3 ? HP : 3;
-  constexpr int EV1 = (HP - HP0) ? NFRAG / (HP - HP0) : 1, EV2 = NFRAG / (PPW - HP);
+  constexpr int D1 = (HP - HP0) > 0 ? (HP - HP0) : 1;
+  constexpr int EV1 = NFRAG / D1, EV2 = NFRAG / (PPW - HP);
   static_assert((HP == HP0 || NFRAG % (HP - HP0) == 0) && NFRAG % (PPW - HP) == 0, "pieces spread evenly over the A fragments of both halves");
   for (uint32_t t = 0; t < NT; ++t) {
     if constexpr (SYNC) {
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8s_kernel(
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     reset_max();
 #pragma unroll
-    for (int w = W0; w < W0 + 33 * SPU; ++w) test_step(acc1, scv[1], scc[1], w);
+    for (int w = W0; w < W0 + (NV + 1) * SPU; ++w) test_step(acc1, scv[1], scc[1], w);
     combine_flags();
     if (VAR == 0 && any_flag()) rare_log(acc1, scv[1], tile_row0(NT - 1), 1);
   }

@@ -703,16 +703,17 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
   }
-#define NVDB_I8S_LAUNCH(SYNCV, PROG, MASK, LEAD)                                                                                  \
+#define NVDB_I8S_LAUNCH(SYNCV, PROG, MASK, LEAD) NVDB_I8S_LAUNCH_W(SYNCV, PROG, MASK, LEAD, 4)
+#define NVDB_I8S_LAUNCH_W(SYNCV, PROG, MASK, LEAD, WPBV)                                                                          \
   {                                                                                                                             \
-    if constexpr (DIM >= 512) {                                                                                                 \
-      constexpr size_t ldss = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + 4 * 256);                                         \
-      const void* fn = reinterpret_cast<const void*>(filter_i8s_kernel<DIM, SYNCV>);                                            \
+    if constexpr (DIM >= 512 && (WPBV == 4 || DIM == 768)) {                                                                    \
+      constexpr size_t ldss = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + WPBV * 256);                                      \
+      const void* fn = reinterpret_cast<const void*>(filter_i8s_kernel<DIM, SYNCV, false, 6, 0, WPBV>);                         \
       if (!c->lds_attr_set.count(fn)) {                                                                                         \
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldss)));                 \
         c->lds_attr_set.insert(fn);                                                                                             \
       }                                                                                                                         \
-      hipExtLaunchKernelGGL((filter_i8s_kernel<DIM, SYNCV>), dim3(nwg), dim3(256), ldss, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
+      hipExtLaunchKernelGGL((filter_i8s_kernel<DIM, SYNCV, false, 6, 0, WPBV>), dim3(nwg), dim3(64 * WPBV), ldss, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
           static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),   \
           static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
     }                                                                                                                           \
@@ -729,10 +730,15 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
 #endif
   const bool defer = c->opt_i8_defer != 0 || c->i8_scales_signed;
   const bool s16 = pipe && !w8 && !defer && c->opt_i8_mfma16 && DIM >= 512;
+  [[maybe_unused]] const bool s16w8 = pipe && w8 && !defer && c->opt_i8_mfma16 && DIM == 768;        // developer build: the 16x16x64 build on 8 waves (d = 768 only; measured equal to 4 waves)
   const uint32_t smask = static_cast<uint32_t>(c->opt_sync_every - 1), slead = static_cast<uint32_t>(c->opt_sync_lead);
   if (sync) {
     uint32_t* prog = nullptr;
     if ((st = next_prog_region(c, s, nwg, &prog))) return st;
+#ifdef NVDB_HIP_DEV
+    if (s16w8) NVDB_I8S_LAUNCH_W(true, prog, smask, slead, 8)
+    else
+#endif
     if (s16) NVDB_I8S_LAUNCH(true, prog, smask, slead)
 #ifdef NVDB_HIP_DEV
     else if (w8) NVDB_I8P_LAUNCH(true, prog, smask, slead, 8, true)              // the 8-wave variant exists with the in-loop second stage only
@@ -741,6 +747,10 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
     else if (pipe) { if constexpr (HAS_I8P32) NVDB_I8P_LAUNCH(true, prog, smask, slead, 4, false) }
     else if constexpr (HAS_I8W) NVDB_I8W_LAUNCH(true, prog, smask, slead)
   } else {
+#ifdef NVDB_HIP_DEV
+    if (s16w8) NVDB_I8S_LAUNCH_W(false, nullptr, 0u, 0u, 8)
+    else
+#endif
     if (s16) NVDB_I8S_LAUNCH(false, nullptr, 0u, 0u)
 #ifdef NVDB_HIP_DEV
     else if (w8) NVDB_I8P_LAUNCH(false, nullptr, 0u, 0u, 8, true)
@@ -752,6 +762,7 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
 #undef NVDB_I8W_LAUNCH
 #undef NVDB_I8P_LAUNCH
 #undef NVDB_I8S_LAUNCH
+#undef NVDB_I8S_LAUNCH_W
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }

@@ -82,7 +82,7 @@ def test_register_budgets_of_the_production_kernels(codegen):
     assert k["agpr"] >= 192 and k["occ"] == 1, k                      # ... with the in-loop second stage (option i8_defer)
     k = _find(by_name, "filter_i8p_kernel<768, true, false, 6, 0, 8, true>")
     assert k["vgpr"] <= 128 and k["agpr"] <= 128 and k["agpr"] >= 96 and k["occ"] == 2, k   # its 8-wave variant (option i8_waves8): 32 queries per wave, two waves per SIMD
-    k = _find(by_name, "filter_i8s_kernel<768, true, false, 6, 0>")
+    k = _find(by_name, "filter_i8s_kernel<768, true, false, 6, 0, 4>")
     assert k["agpr"] >= 192 and k["occ"] == 1 and k["sspill"] == 0, k  # the product's int8 batch-1024 kernel (16x16x64 MFMA): hi plane of 64 queries in AGPRs
     # exact fp32-order scores on the fp32 matrix cores: 16 queries x 768 floats stationary (192 registers) + a tile of raw rows in flight
     for name in ("scan_exact_mfma_kernel<2, 768>", "scan_exact_mfma_kernel<1, 768>", "scan_exact_mfma_kernel<3, 768>", "scores_exact_mfma_kernel<2, 768>"):
@@ -126,7 +126,7 @@ def test_rendezvous_registers_and_hand_placed_instructions(codegen):
     k = _find(by_name, "scan_exact_mfma_kernel<2, 768>")
     body = _body(asm, k["mangled"])
     assert body.count("v_mfma_f32_16x16x4_f32") == 192 and body.count("s_waitcnt vmcnt(23)") >= 24, (body.count("v_mfma_f32_16x16x4_f32"), body.count("s_waitcnt vmcnt(23)"))
-    k = _find(by_name, "filter_i8s_kernel<768, true, false, 6, 0>")
+    k = _find(by_name, "filter_i8s_kernel<768, true, false, 6, 0, 4>")
     body = _body(asm, k["mangled"])
     assert body.count("v_mfma_i32_16x16x64_i8") == 192 and "v_mfma_i32_32x32x32_i8" not in body
     # refine v3: q - half as ONE v_fma_mix_f32 per element (hipcc folds the C++ form back into cvt + sub)

@@ -229,7 +229,7 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx_dev, oracle, nq, k, 
     # after the stream (the default); 2: two-stage, filter_i8w_kernel; 3: the pipelined build with the in-loop second stage
     # (deferred v_dot4 slots); 4: the same on 8 waves of 32 queries; 5: the product's default: the logged build on
     # v_mfma_i32_16x16x64_i8 (d >= 512; d = 256 keeps the 32x32x32 build)
-    variants = ((0, 1, 0, 0, 0), (1, 1, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 0, 1, 0), (1, 1, 1, 1, 0), (1, 1, 0, 0, 1))
+    variants = ((0, 1, 0, 0, 0), (1, 1, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 0, 1, 0), (1, 1, 1, 1, 0), (1, 1, 0, 0, 1), (1, 1, 1, 0, 1))   # last: 16x16x64 on 8 waves (d = 768)
     for var, (wide, pipe, w8, defer, m16) in enumerate(variants):
         ctx.set_option("i8_wide", wide)
         ctx.set_option("i8_pipe", pipe)

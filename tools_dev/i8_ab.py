@@ -15,7 +15,7 @@ q = torch.from_numpy(nvdb_amd.synth_rows_f32(20240614, 0, 4 * B, d)).to(dev)
 oi = torch.empty((B, K), dtype=torch.int64, device=dev); os_ = torch.empty((B, K), dtype=torch.float32, device=dev)
 ref = None
 for rnd in range(3):
-    for pipe, w8, defer, m16 in ((1, 0, 0, 0), (1, 0, 0, 1), (1, 0, 1, 0), (1, 0, 0, 1), (1, 0, 0, 0)):
+    for pipe, w8, defer, m16 in ((1, 0, 0, 1), (1, 1, 0, 1), (1, 0, 0, 0), (1, 1, 0, 1), (1, 0, 0, 1)):
         ctx.set_option("i8_pipe", pipe)
         ctx.set_option("i8_mfma16", m16)
         ctx.set_option("i8_waves8", w8)
