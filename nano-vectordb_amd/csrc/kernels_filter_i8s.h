@@ -25,7 +25,8 @@ typedef int intx4_t __attribute__((ext_vector_type(4)));
 #define NVDB_MFMA_I8S_FROM(acc, a, b, c0) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c0))
 #define NVDB_MFMA_I8S_ACC(acc, a, b) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 
-// VAR (STAMP builds only; wrong results): 1 = no test, no logging (structure alone), 2 = test, nothing logged.
+// VAR (STAMP builds only; wrong results): 1 = no test, no logging (structure alone), 2 = test, nothing logged,
+// 3 = structure alone without the in-loop LDS-DMA issue (the stages keep the first tiles), 4 = structure alone without the A-fragment LDS reads.
 // WPB = 8: the same 256 queries per workgroup on 8 waves of 32 (two waves per SIMD, 128 + 128 registers each): a wave's LDS-DMA issue,
 // ring priming and barrier waits run beside its SIMD partner's MFMAs.
 template <int DIM, bool SYNC = false, bool STAMP = false, int RING = 6, int VAR = 0, int WPB = 4>
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
     const float* __restrict__ qdelta, Hit* __restrict__ hitlog, ScatterArgs sa, uint32_t* __restrict__ prog,
     uint32_t sync_mask, uint32_t sync_lead, uint32_t* __restrict__ stage_counts) {
   static_assert(WPB == 4 || WPB == 8, "4 waves x 64 queries or 8 waves x 32 queries");
+  constexpr bool NOTEST = VAR == 1 || VAR == 3 || VAR == 4;
   constexpr int NB = 16 / WPB, MB = 2;                       // blocks of 16 queries per wave; 2 blocks of 32 rows per tile
   constexpr int NV = 8 * NB;                                 // values a lane tests per 32-row block
   constexpr int KS = DIM / 64;                               // k-steps of 64 bytes
@@ -118,6 +120,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
   auto issue_scales = [&](uint32_t row0, uint32_t buf) {
     if (lane < 8 * MB) glds16(sc_off, reinterpret_cast<const char*>(scales + row0), lds_base + buf * STAGE_BYTES + DATA_BYTES + wave * 256);
   };
+  auto loop_piece = [&](uint32_t row0, uint32_t buf, int i) { if constexpr (VAR != 3) issue_piece(row0, buf, i); };
+  auto loop_scales = [&](uint32_t row0, uint32_t buf) { if constexpr (VAR != 3) issue_scales(row0, buf); };
 #pragma unroll
   for (int st = 0; st < NSTAGE - 1; ++st) {
 #pragma unroll
@@ -144,12 +148,13 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
 
   auto read_a = [&](const char* stage, int u, int mb) -> float4_t {         // u = 2 s + h: k-step s, 16-row half h of row block mb
     const int s = u >> 1, h = u & 1;
+    if constexpr (VAR == 4) { float4_t z = {0.f, 1.f, 2.f, 3.f}; asm volatile("" : "+v"(z)); return z; }
     return *reinterpret_cast<const float4_t*>(stage + (a16 ^ ((s & 3) << 6)) + (s >> 2) * 256 + (2 * mb + h) * 16 * ROW_BYTES);
   };
   // in the shadow of the MFMAs: slot 0 reads the 8 scales of block mb of `stage` into set `set`, slots SW0.. multiply one each by -2^23
   constexpr int SW0 = 8;
   auto scale_step = [&](const char* stage, int mb, int set, int w) {
-    if constexpr (VAR == 1) return;
+    if constexpr (NOTEST) return;
     if (w == 0) {
       const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 256);
 #pragma unroll
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
   constexpr int SPU = (NSLOT - W0 - 4) / NV >= 2 ? 2 : 1;   // slots per unit
   static_assert(W0 + NV * SPU + 2 <= NSLOT, "the test ends before the half's last MFMA");
   auto test_step = [&](const intx4_t (&a)[2][NB], const float (&sc)[8], const float (&sccs)[8], int w) {
-    if constexpr (VAR == 1) return;
+    if constexpr (NOTEST) return;
     const int rel = w - W0;
     if (rel < 0 || rel % SPU != 0) return;
     const int v = rel / SPU;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
   };
   float flagv = -1.f;                              // >= 0 iff some value of the tested block reaches its first-stage threshold
   auto combine_flags = [&]() {
-    if constexpr (VAR == 1) return;
+    if constexpr (NOTEST) return;
     float m[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) m[nb] = vmax3(mx[nb][0], mx[nb][1], mx[nb][1]) - t1q[nb];
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
 #pragma unroll
     for (int u = 0; u < RING - 1; ++u) ar[u] = read_a(stage, u, 0);
 #pragma unroll
-    for (int i = 0; i < HP0; ++i) issue_piece(next_row0, next_buf, i);
+    for (int i = 0; i < HP0; ++i) loop_piece(next_row0, next_buf, i);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < NFRAG; ++u) {
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (HP > HP0) {
-        if (u % EV1 == EV1 - 1) issue_piece(next_row0, next_buf, HP0 + u / EV1);
+        if (u % EV1 == EV1 - 1) loop_piece(next_row0, next_buf, HP0 + u / EV1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -289,8 +294,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
         if (w == NSLOT - 1) combine_flags();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (u % EV2 == EV2 - 1) issue_piece(next_row0, next_buf, HP + u / EV2);
-      if (u == 0) issue_scales(next_row0, next_buf);
+      if (u % EV2 == EV2 - 1) loop_piece(next_row0, next_buf, HP + u / EV2);
+      if (u == 0) loop_scales(next_row0, next_buf);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (VAR == 0 && any_flag()) rare_log(acc0, scv[0], tile_row0(t), 0);

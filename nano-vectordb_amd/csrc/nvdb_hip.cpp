@@ -1797,7 +1797,7 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
   const size_t prog_bytes = static_cast<size_t>(nwg) * 8 * 4, stamp_bytes = static_cast<size_t>(nwg) * 16;
   nvdb_status st;
   if ((st = ensure(c, c->prog, std::max(prog_bytes + stamp_bytes, static_cast<size_t>(PROG_SLOTS) * c->num_cu * 8 * 4)))) return st;
-  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 4 * FILTER_LOGCAP * sizeof(Hit)))) return st;
+  if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 8 * FILTER_LOGCAP * sizeof(Hit)))) return st;
   constexpr size_t lds = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + 4 * 1024) + 4096;
   const uint64_t n_dbg = c->dbg_rows > 0 ? std::min<uint64_t>(c->n, static_cast<uint64_t>(c->dbg_rows)) : c->n;
   const uint32_t n_al = static_cast<uint32_t>(n_dbg / I8W_TILE_ROWS * I8W_TILE_ROWS);
@@ -1848,13 +1848,14 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
       case 13: NVDB_CLK_I8P(3, true) break;             // ... rare path, deferred values never consumed
       case 14: NVDB_CLK_I8P(4, true) break;             // ... rare path entered and left at once
       case 15: NVDB_CLK_I8P(5, true) break;             // ... production loop, cycles inside rare_path / consume_slots (wave 0 of every workgroup)
-#define NVDB_CLK_I8S(V)                                                                                                          \
+#define NVDB_CLK_I8S(V) NVDB_CLK_I8SW(V, 4)
+#define NVDB_CLK_I8SW(V, W)                                                                                                      \
       {                                                                                                                          \
-        constexpr size_t ldss = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + 4 * 256);                                        \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_i8s_kernel<768, true, true, 6, V>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldss))); \
+        constexpr size_t ldss = static_cast<size_t>(3) * (I8W_TILE_ROWS * 768 + W * 256);                                        \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(filter_i8s_kernel<768, true, true, 6, V, W>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldss))); \
         for (uint32_t r = 0; r < burst; ++r) {                                                                                   \
           HIPCHK(c, hipMemsetAsync(c->prog.p, 0xFF, prog_bytes, c->stream));                                                     \
-          filter_i8s_kernel<768, true, true, 6, V><<<nwg, 256, ldss, c->stream>>>(                                               \
+          filter_i8s_kernel<768, true, true, 6, V, W><<<nwg, 64 * W, ldss, c->stream>>>(                                         \
               filter_rows_i8(c), filter_scales_i8(c), 0, n_al, qhi, qlo, nq, QT, static_cast<const float*>(c->thr.p),            \
               static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p), static_cast<const float*>(c->qdelta.p), \
               static_cast<Hit*>(c->hitlog.p), scatter_args(c, c->last_cap, I8W_TILE_ROWS), static_cast<uint32_t*>(c->prog.p),    \
@@ -1864,6 +1865,10 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
       case 30: NVDB_CLK_I8S(0) break;                // the 16x16x64 build (kernels_filter_i8s.h), stamped
       case 31: NVDB_CLK_I8S(1) break;                // ... its structure alone: no test, nothing logged
       case 32: NVDB_CLK_I8S(2) break;                // ... test, nothing logged
+      case 33: NVDB_CLK_I8S(3) break;                // ... structure alone without the in-loop LDS-DMA issue
+      case 34: NVDB_CLK_I8S(4) break;                // ... structure alone without the A-fragment LDS reads
+      case 35: NVDB_CLK_I8SW(0, 8) break;            // the 8-wave 16x16x64 build, stamped
+      case 36: NVDB_CLK_I8SW(1, 8) break;            // ... its structure alone
       case 20: NVDB_CLK_I8P(0, false) break;         // the default build (first-stage survivors logged, finished after the stream), stamped
       case 22: NVDB_CLK_I8P(2, false) break;         // ... test, nothing logged
       case 24: NVDB_CLK_I8P(4, false) break;         // ... logging entered and left at once
@@ -1882,6 +1887,7 @@ nvdb_status nvdb_hip_debug_clock_i8(nvdb_hip_ctx* c, int variant, uint32_t nq, f
 #undef NVDB_CLK_I8
 #undef NVDB_CLK_I8P
 #undef NVDB_CLK_I8S
+#undef NVDB_CLK_I8SW
   std::vector<uint64_t> stamps(static_cast<size_t>(nwg) * 2);
   HIPCHK(c, hipMemcpy(stamps.data(), static_cast<const char*>(c->prog.p) + prog_bytes, stamp_bytes, hipMemcpyDeviceToHost));
   std::vector<float> ghz;

@@ -17,7 +17,7 @@ q = nvdb_amd.synth_rows_f32(20240614, 0, nq, 768)
 ctx.set_option("path", 2); ctx.search_batch(q, 10)
 st = ctx.stats()
 print(f"search: {st}", flush=True)
-names = {30: "16x16x64 build (kernels_filter_i8s.h)", 31: "16x16x64 build, structure alone (no test, nothing logged)", 32: "16x16x64 build, test only", 20: "pipelined build, first-stage survivors logged and finished after the stream (the default)", 22: "default build, test only (nothing logged)", 24: "default build, logging entered and left at once", 10: "pipelined build with the in-loop second stage (i8_defer=1)", 11: "pipelined structure alone (no test, no rare path)", 12: "pipelined, test in the MFMA shadow, rare path never taken", 13: "pipelined, rare path without consuming the deferred values", 14: "pipelined, rare path entered and left at once", 0: "filter_i8w_kernel loop", 1: "no stage 2 (lo plane never multiplied)", 2: "no stage-1 test either (stream + hi-plane MFMAs)", 3: "the same without the per-tile barrier"}
+names = {33: "16x16x64 build, structure alone WITHOUT the in-loop LDS-DMA issue", 34: "16x16x64 build, structure alone WITHOUT the A-fragment LDS reads", 35: "16x16x64 build on 8 waves", 36: "16x16x64 build on 8 waves, structure alone", 30: "16x16x64 build (kernels_filter_i8s.h)", 31: "16x16x64 build, structure alone (no test, nothing logged)", 32: "16x16x64 build, test only", 20: "pipelined build, first-stage survivors logged and finished after the stream (the default)", 22: "default build, test only (nothing logged)", 24: "default build, logging entered and left at once", 10: "pipelined build with the in-loop second stage (i8_defer=1)", 11: "pipelined structure alone (no test, no rare path)", 12: "pipelined, test in the MFMA shadow, rare path never taken", 13: "pipelined, rare path without consuming the deferred values", 14: "pipelined, rare path entered and left at once", 0: "filter_i8w_kernel loop", 1: "no stage 2 (lo plane never multiplied)", 2: "no stage-1 test either (stream + hi-plane MFMAs)", 3: "the same without the per-tile barrier"}
 for var in ([int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (20, 24, 22, 11, 10, 20, 24, 22)):
     out = (C.c_float * 8)()
     rc = lib.nvdb_hip_debug_clock_i8(ctx.h, var, nq, secs, out)
