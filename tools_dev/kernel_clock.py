@@ -11,7 +11,7 @@ secs = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
 ctx = nvdb_amd.HipContext(0, dev=True)            # libnvdb_hip_dev.so
 ctx.generate_corpus(20240613, n, 768, nvdb_amd.DT_F16)
 lib = ctx.lib
-for nq in (1024,):
+for nq in [int(x) for x in os.environ.get("CLOCK_NQ", "1024").split(",")]:          # CLOCK_NQ=1024,512,256: the query tiles per stream 4 / 2 / 1
     q = nvdb_amd.synth_rows_f32(1, 0, nq, 768)
     ctx.set_option("path", 2)
     for bal, var, name in ((0, 20, "8-wave build, equal tile shares"), (1, 20, "8-wave build (default at d=768), XCD-balanced shares"), (1, 0, "4-wave build, XCD-balanced"),
