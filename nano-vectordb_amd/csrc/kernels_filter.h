@@ -992,6 +992,22 @@ __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ 
   }
 }
 
+// LDS image of an int8 tile: chunk c (16 bytes) of row r sits at chunk position swz_chunk(c, r) of its row, so that the 16 rows a
+// ds_read_b128 group touches at one k-offset fall into 16 different 16-byte bank groups.  Row strides that are multiples of 256
+// bytes start every row in the same bank group: c ^ (r & 15).  Odd multiples of 128 bytes (d = 384, the reference's own data
+// dimension) start consecutive rows 8 bank groups apart -- (r & 1) already picks the half, (r >> 1) & 7 the place inside it.
+template <int ROW_BYTES> __device__ constexpr bool swz16() { return (ROW_BYTES / 16) % 16 == 0; }
+template <int ROW_BYTES> __device__ inline uint32_t swz_chunk(uint32_t c, uint32_t r) {
+  static_assert(ROW_BYTES % 128 == 0, "int8 row stride: a multiple of 128 bytes");
+  return swz16<ROW_BYTES>() ? c ^ (r & 15u) : c ^ ((r >> 1) & 7u);
+}
+// v_mfma_i32_32x32x32_i8 A fragment of k-step s: chunk 2 s + hsel of row r31; 2 s + hsel == 2 s ^ hsel, so the swizzled position is
+// a_base ^ (the k-step's bits inside the swizzle group) + the byte offset of the group
+template <int ROW_BYTES> __device__ inline uint32_t a_base_i8(uint32_t r31, uint32_t hsel) { return r31 * ROW_BYTES + (swz_chunk<ROW_BYTES>(hsel, r31) << 4); }
+template <int ROW_BYTES> __device__ inline uint32_t a_addr_i8(uint32_t a_base, int s) {
+  return swz16<ROW_BYTES>() ? (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256 : (a_base ^ ((s & 3) << 5)) + (s >> 2) * 128;
+}
+
 #define NVDB_MFMA_I8_ZERO(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b))
 #define NVDB_MFMA_I8_ACC(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 // first k-step of a block whose accumulators start at a constant (16 VGPRs holding it: srcC and vDst share a register class)
@@ -1012,7 +1028,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
   constexpr int PIECES = DATA_BYTES / 1024;
   constexpr int PPW = PIECES / 4;                  // corpus pieces per wave
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
-  static_assert(DIM % 256 == 0, "swizzle assumes the int8 row stride is a multiple of 256 bytes");
+  static_assert(DIM % 128 == 0, "int8 row stride: a multiple of 128 bytes (swz_chunk)");
   static_assert(PIECES % 4 == 0 && KSTEPS % PPW == 0 && 2 * KSTEPS <= 64, "shape");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1056,10 +1072,10 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
   for (int i = 0; i < PPW; ++i) {
     const uint32_t P = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
     const uint32_t r = P / CHUNKS_PER_ROW, cpos = P % CHUNKS_PER_ROW;
-    src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
+    src_off[i] = r * ROW_BYTES + (swz_chunk<ROW_BYTES>(cpos, r) << 4);
   }
   const uint32_t sc_off = (lane & 7) * 16;         // 32 row scales = 128 bytes; lanes >= 8 re-load the same chunks
-  const uint32_t a_base = r31 * ROW_BYTES + ((static_cast<uint32_t>(hsel) ^ (r31 & 15u)) << 4);
+  const uint32_t a_base = a_base_i8<ROW_BYTES>(static_cast<uint32_t>(r31), static_cast<uint32_t>(hsel));
 
   const char* gbase = reinterpret_cast<const char*>(rows);
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
@@ -1100,7 +1116,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8_kernel(
       continue;
     }
     auto read_a = [&](int s) -> float4_t {
-      return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256);
+      return *reinterpret_cast<const float4_t*>(stage + a_addr_i8<ROW_BYTES>(a_base, s));
     };
     // this tile's 16 row scales for my lanes: read now, used in the epilogue (their latency hides behind the MFMAs)
     const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 1024);
@@ -1233,7 +1249,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   // dims up to 1536 (768 < DIM: NB = 1, MB = 1 -- 32 queries per wave, 192 AGPRs of hi-plane fragments, 32-row tiles in three
   // 52 KB stages).  int32 range of (H << 7) + L at any dim: prep_q8_kernel keeps the L1 norm of a query's hi plane below
   // I8_HI_L1_MAX, so |H| < 2^23 whatever the dim.
-  static_assert(DIM % 256 == 0 && DIM <= 1536 && (DIM <= 768 || (NB == 1 && MB == 1)), "row stride multiple of 256 bytes; fragments of one wave <= 192 registers");
+  static_assert(DIM % 128 == 0 && DIM <= 1536 && (DIM <= 768 || (NB == 1 && MB == 1)), "row stride multiple of 128 bytes (swz_chunk); fragments of one wave <= 192 registers");
   static_assert(PIECES % 4 == 0 && (MB * KSTEPS) % PPW == 0 && NB * KSTEPS <= 64 && KSTEPS % 2 == 0, "shape");
   static_assert(NB == 1 || NB == 2, "one or two 32-query blocks per wave");
   static_assert((MB == 1 || MB == 2) && NSTAGE * STAGE_BYTES <= 160 * 1024 && (NSTAGE - 2) * (PPW + 1) < 64, "LDS / vmcnt range");
@@ -1287,10 +1303,10 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
   for (int i = 0; i < PPW; ++i) {
     const uint32_t P = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
     const uint32_t r = P / CHUNKS_PER_ROW, cpos = P % CHUNKS_PER_ROW;
-    src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
+    src_off[i] = r * ROW_BYTES + (swz_chunk<ROW_BYTES>(cpos, r) << 4);
   }
   const uint32_t sc_off = (lane & (8 * MB - 1)) * 16;   // TROWS row scales = 128 * MB bytes; the other lanes re-load the same chunks
-  const uint32_t a_base = r31 * ROW_BYTES + ((static_cast<uint32_t>(hsel) ^ (r31 & 15u)) << 4);
+  const uint32_t a_base = a_base_i8<ROW_BYTES>(static_cast<uint32_t>(r31), static_cast<uint32_t>(hsel));
 
   const char* gbase = reinterpret_cast<const char*>(rows);
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
@@ -1370,7 +1386,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
     }
     auto read_a = [&](int u) -> float4_t {        // u = MB*s + mb: k-step s of row block mb
       const int s = u / MB, mb = u % MB;
-      return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256 + mb * FILTER_ROWS * ROW_BYTES);
+      return *reinterpret_cast<const float4_t*>(stage + a_addr_i8<ROW_BYTES>(a_base, s) + mb * FILTER_ROWS * ROW_BYTES);
     };
     // this tile's 16 row scales per row block for my lanes (rows 32*mb + (r&3) + 8*(r>>2) + 4*hsel)
     const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + wave * 1024);
@@ -1455,7 +1471,7 @@ __global__ __launch_bounds__(256, 1) void filter_i8w_kernel(
         }
       if (nflag == 1) {
         // its corpus row: chunk l of row i sits at position l ^ (i & 15) of the stage's row image
-        if (lane < DIM / 16) pend_x = *reinterpret_cast<const uint4*>(stage + pend_row * ROW_BYTES + ((static_cast<uint32_t>(lane) ^ (pend_row & 15u)) << 4));
+        if (lane < DIM / 16) pend_x = *reinterpret_cast<const uint4*>(stage + pend_row * ROW_BYTES + (swz_chunk<ROW_BYTES>(static_cast<uint32_t>(lane), pend_row) << 4));
         if (lane < DIM / 16) glds16(static_cast<uint32_t>(lane) * 16u, qlo + static_cast<uint64_t>(pend_qid) * DIM, lds_scratch);
         pend_row += row0;
         pend = true;
@@ -1630,7 +1646,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
   constexpr int PIECES = DATA_BYTES / 1024;
   constexpr int PPW = PIECES / WPB;
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
-  static_assert(DIM % 256 == 0 && DIM <= 768, "row stride multiple of 256 bytes; int32 range of 128*H + L");
+  static_assert(DIM % 128 == 0 && DIM <= 768, "row stride multiple of 128 bytes (swz_chunk); int32 range of 128*H + L");
   static_assert(PIECES % WPB == 0 && KSTEPS % PPW == 0 && KSTEPS % 2 == 0 && KSTEPS >= 8, "shape");
   static_assert(NSTAGE * STAGE_BYTES + WPB * SCRATCH_BYTES <= 160 * 1024 && PPW + 1 < 64 && DIM % 16 == 0 && DIM / 16 <= 64, "LDS / vmcnt range");
 
@@ -1692,10 +1708,10 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
   for (int i = 0; i < PPW; ++i) {
     const uint32_t P = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
     const uint32_t r = P / CHUNKS_PER_ROW, cpos = P % CHUNKS_PER_ROW;
-    src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
+    src_off[i] = r * ROW_BYTES + (swz_chunk<ROW_BYTES>(cpos, r) << 4);
   }
   const uint32_t sc_off = (lane & (8 * MB - 1)) * 16;
-  const uint32_t a_base = r31 * ROW_BYTES + ((static_cast<uint32_t>(hsel) ^ (r31 & 15u)) << 4);
+  const uint32_t a_base = a_base_i8<ROW_BYTES>(static_cast<uint32_t>(r31), static_cast<uint32_t>(hsel));
 
   const char* gbase = reinterpret_cast<const char*>(rows);
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
@@ -1777,7 +1793,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
 
   // one 32-row block's MFMAs (KSTEPS k-steps x NB query blocks) with `slot(s)` called after every k-step
   auto read_a = [&](const char* stage, int s, int mb) -> float4_t {
-    return *reinterpret_cast<const float4_t*>(stage + (a_base ^ ((s & 7) << 5)) + (s >> 3) * 256 + mb * FILTER_ROWS * ROW_BYTES);
+    return *reinterpret_cast<const float4_t*>(stage + a_addr_i8<ROW_BYTES>(a_base, s) + mb * FILTER_ROWS * ROW_BYTES);
   };
   auto load_scales = [&](const char* stage, int mb, float (&dst)[16]) {
     const float* sc_lds = reinterpret_cast<const float*>(stage + DATA_BYTES + (wave % SC_COPIES) * 256);
@@ -1899,7 +1915,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
             pend_qid[i] = readlane_u(qid[nb], L);
             pend_row[i] = rowi + row0;
             // its corpus row: chunk l of row i sits at position l ^ (i & 15) of the stage's row image
-            if (lane < DIM / 16) pend_x[i] = *reinterpret_cast<const uint4*>(stage + rowi * ROW_BYTES + ((static_cast<uint32_t>(lane) ^ (rowi & 15u)) << 4));
+            if (lane < DIM / 16) pend_x[i] = *reinterpret_cast<const uint4*>(stage + rowi * ROW_BYTES + (swz_chunk<ROW_BYTES>(static_cast<uint32_t>(lane), rowi) << 4));
             if (lane < DIM / 16) glds16(static_cast<uint32_t>(lane) * 16u, qlo + static_cast<uint64_t>(pend_qid[i]) * DIM, lds_scratch + i * DIM);
             pend_mask |= 1u << i;
             ++issued;
@@ -1993,7 +2009,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
     // <= 3 VALU instructions inside the MFMA's 24 free issue cycles).  The A-fragment ring is primed per half: keeping it
     // alive across the rare path between the halves costs more registers than the file has.
     constexpr int NUNIT = NV;                                              // test units: values
-    constexpr int NSLOT = NB * KSTEPS, W0 = NB == 1 ? (NSLOT / 6 < 4 ? NSLOT / 6 : 4) : (NSLOT / 4 < 8 ? NSLOT / 4 : 8), VPS = (NUNIT + NSLOT - W0 - 4) / (NSLOT - W0 - 3);   // units per slot: 1 at d = 768
+    constexpr int NSLOT = NB * KSTEPS, W0 = NB == 1 ? (NSLOT / 6 < 4 ? NSLOT / 6 : 4) : (NSLOT < 32 ? 4 : 8), VPS = (NUNIT + NSLOT - W0 - 4) / (NSLOT - W0 - 3);   // units per slot: 1 at d = 768
     static_assert(VPS >= 1 && W0 + (NUNIT + VPS - 1) / VPS + 1 <= NSLOT - 2 && (VPS == 1 || VPS % 2 == 0 || BIASED), "the three test stages end before the half's last MFMA");
     // LDS-DMA issue of tile t+2.  DEFER: all of it in the second half, behind barrier B.  Otherwise spread over both halves (one
     // piece costs ~60 issue cycles; beside the second half's MFMAs, test and ring reads a wave has room for half of them).
@@ -2168,8 +2184,8 @@ __global__ __launch_bounds__(256) void shadow_f16_kernel(const SrcT* __restrict_
   if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(maxabs_bits, __builtin_bit_cast(uint32_t, mx));
 }
 
-// int8 corpus whose dim is not 256 / 512 / 768: copy with rows zero-padded to sdim bytes (the swizzled LDS image
-// needs a row stride that is a multiple of 256 bytes); 16 source bytes per thread where alignment allows
+// int8 corpus whose dim the kernels are not instantiated for: copy with rows zero-padded to sdim bytes (the swizzled LDS image
+// needs a row stride that is a multiple of 128 bytes, swz_chunk); 16 source bytes per thread where alignment allows
 __global__ __launch_bounds__(256) void shadow_i8_kernel(const signed char* __restrict__ src, signed char* __restrict__ dst, size_t n,
                                                         uint32_t dim, uint32_t sdim) {
   const size_t count = n * sdim;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
   constexpr int CHUNKS_PER_ROW = ROW_BYTES / 16;
   constexpr int NSLOT = 2 * NB * KS;                         // MFMAs (16 cycles each) per 32-row block
   constexpr int NFRAG = 2 * KS;                              // A fragments per 32-row block
-  static_assert(DIM % 256 == 0 && DIM <= 768, "row stride multiple of 256 bytes; 64 queries x DIM bytes = 192 AGPRs at most");
+  static_assert(DIM % 128 == 0 && DIM <= 768, "row stride multiple of 128 bytes (swz_chunk); 64 queries x DIM bytes = 192 AGPRs at most");
   static_assert(PIECES % WPB == 0 && PPW % 2 == 0 && NSTAGE * STAGE_BYTES <= 160 * 1024 && PPW + 1 < 64 && NFRAG >= RING, "shape / LDS / vmcnt range");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,11 +104,12 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
   for (int i = 0; i < PPW; ++i) {
     const uint32_t P = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
     const uint32_t r = P / CHUNKS_PER_ROW, cpos = P % CHUNKS_PER_ROW;
-    src_off[i] = r * ROW_BYTES + ((cpos ^ (r & 15u)) << 4);
+    src_off[i] = r * ROW_BYTES + (swz_chunk<ROW_BYTES>(cpos, r) << 4);
   }
   const uint32_t sc_off = (lane & (8 * MB - 1)) * 16;
-  // A fragment (rb, s): chunk 4 s + g4 of row 16 rb + x15 at position (4 s + g4) ^ x15:  a16 ^ ((s & 3) << 6)  +  256 (s >> 2)  +  16 ROW_BYTES rb
-  const uint32_t a16 = static_cast<uint32_t>(x15) * ROW_BYTES + ((static_cast<uint32_t>(g4) ^ static_cast<uint32_t>(x15)) << 4);
+  // A fragment (rb, s): chunk 4 s + g4 of row 16 rb + x15 at position swz_chunk(4 s + g4, x15):  a16 ^ ((s & 3) << 6)  +  256 (s >> 2)  +  16 ROW_BYTES rb
+  // (row strides that are odd multiples of 128 bytes, d = 384: the swizzle group is 8 chunks, a16 ^ ((s & 1) << 6)  +  128 (s >> 1))
+  const uint32_t a16 = static_cast<uint32_t>(x15) * ROW_BYTES + (swz_chunk<ROW_BYTES>(static_cast<uint32_t>(g4), static_cast<uint32_t>(x15)) << 4);
 
   const char* gbase = reinterpret_cast<const char*>(rows);
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem)));
@@ -149,10 +150,11 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8s_kernel(
   auto read_a = [&](const char* stage, int u, int mb) -> float4_t {         // u = 2 s + h: k-step s, 16-row half h of row block mb
     const int s = u >> 1, h = u & 1;
     if constexpr (VAR == 4) { float4_t z = {0.f, 1.f, 2.f, 3.f}; asm volatile("" : "+v"(z)); return z; }
-    return *reinterpret_cast<const float4_t*>(stage + (a16 ^ ((s & 3) << 6)) + (s >> 2) * 256 + (2 * mb + h) * 16 * ROW_BYTES);
+    const uint32_t off = swz16<ROW_BYTES>() ? (a16 ^ ((s & 3) << 6)) + (s >> 2) * 256 : (a16 ^ ((s & 1) << 6)) + (s >> 1) * 128;
+    return *reinterpret_cast<const float4_t*>(stage + off + (2 * mb + h) * 16 * ROW_BYTES);
   };
   // in the shadow of the MFMAs: slot 0 reads the 8 scales of block mb of `stage` into set `set`, slots SW0.. multiply one each by -2^23
-  constexpr int SW0 = 8;
+  constexpr int SW0 = NSLOT >= 64 ? 8 : 4;         // (d = 384: 48 slots per half; the 32 test units need 34 of them)
   auto scale_step = [&](const char* stage, int mb, int set, int w) {
     if constexpr (NOTEST) return;
     if (w == 0) {

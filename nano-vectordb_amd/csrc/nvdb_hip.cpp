@@ -185,7 +185,7 @@ bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 38
 constexpr uint32_t F16_FILTER_MAX_DIM = 3072;
 constexpr uint32_t I8W_TILE_ROWS = 64;                // rows per tile of the int8 two-stage kernel (two 32-row blocks)
 constexpr uint32_t PAD_ROWS = 64;                     // zero rows every library-owned corpus / shadow is padded with: the largest tile
-bool i8_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 256 || dim == 1024 || dim == 1280 || dim == 1536; }   // int8 rows: stride % 256 == 0
+bool i8_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 1024 || dim == 1280 || dim == 1536; }   // int8 rows: stride % 128 == 0 (swz_chunk)
 constexpr uint32_t I8_FILTER_MAX_DIM = 1536;
 bool refine3_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256; }   // fp16 dims of the whole-row refine kernel
 
@@ -228,7 +228,7 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   }
   if (c->dtype == NVDB_DTYPE_I8 && c->dim <= I8_FILTER_MAX_DIM && !i8_filter_dim(c->dim) && c->opt_f32_shadow) {
     uint32_t sdim = 256;
-    while (sdim < c->dim) sdim += 256;
+    while (!i8_filter_dim(sdim) || sdim < c->dim) sdim += 128;
     const size_t count = static_cast<size_t>(c->n) * sdim, pad = static_cast<size_t>(PAD_ROWS) * sdim + 4096;
     const size_t n_pad = (static_cast<size_t>(c->n) + PAD_ROWS - 1) / PAD_ROWS * PAD_ROWS + PAD_ROWS;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow8), count + pad));
@@ -692,6 +692,7 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   }
 #define NVDB_I8P_LAUNCH(SYNCV, PROG, MASK, LEAD, WPBV, DEFERV)                                                                            \
   {                                                                                                                             \
+   if constexpr (WPBV == 4 || DIM != 384) {           /* (the 8-wave developer build has no d = 384 schedule) */                \
     /* stages (tile + scale copies) + per wave the deferred lo-plane rows: 4 waves x 4, 8 waves x 2 */                           \
     constexpr size_t ldsp = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + (WPBV == 4 ? 4 : 1) * 256) + (DEFERV ? 16 * DIM : 0); \
     const void* fn = reinterpret_cast<const void*>(filter_i8p_kernel<DIM, SYNCV, false, 6, 0, WPBV, DEFERV>);                           \
@@ -702,11 +703,12 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
     hipExtLaunchKernelGGL((filter_i8p_kernel<DIM, SYNCV, false, 6, 0, WPBV, DEFERV>), dim3(nwg), dim3(64 * WPBV), ldsp, s, c->launch_e0, c->launch_e1, 0, filter_rows_i8(c), filter_scales_i8(c), row_lo, row_hi, qhi, qlo, nq, QT, \
         static_cast<const float*>(c->thr.p), static_cast<const float*>(c->qscale.p), static_cast<const float*>(c->qinv.p),     \
         static_cast<const float*>(c->qdelta.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, I8W_TILE_ROWS), PROG, MASK, LEAD, counts); \
+   }                                                                                                                            \
   }
 #define NVDB_I8S_LAUNCH(SYNCV, PROG, MASK, LEAD) NVDB_I8S_LAUNCH_W(SYNCV, PROG, MASK, LEAD, 4)
 #define NVDB_I8S_LAUNCH_W(SYNCV, PROG, MASK, LEAD, WPBV)                                                                          \
   {                                                                                                                             \
-    if constexpr (DIM >= 512 && (WPBV == 4 || DIM == 768)) {                                                                    \
+    if constexpr (DIM >= 384 && (WPBV == 4 || DIM == 768)) {                                                                    \
       constexpr size_t ldss = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + WPBV * 256);                                      \
       const void* fn = reinterpret_cast<const void*>(filter_i8s_kernel<DIM, SYNCV, false, 6, 0, WPBV>);                         \
       if (!c->lds_attr_set.count(fn)) {                                                                                         \
@@ -720,16 +722,16 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   }
 #ifdef NVDB_HIP_DEV
   const bool pipe = (NB == 2) && c->opt_i8_pipe;         // developer build: i8_pipe = 0 runs filter_i8w_kernel at 64 queries per wave, i8_waves8 = 1 the 8-wave pipelined build
-  const bool w8 = pipe && c->opt_i8_waves8;
+  const bool w8 = pipe && c->opt_i8_waves8 && DIM != 384;
   constexpr bool HAS_I8W = true, HAS_I8P32 = true;
 #else
   const bool pipe = (NB == 2);
   constexpr bool w8 = false;
   constexpr bool HAS_I8W = (NB == 1);                    // the product runs filter_i8w_kernel for batches <= 128 only
-  constexpr bool HAS_I8P32 = (DIM < 512);                // ... and the 32x32x32 logged build only where the 16x16x64 build does not exist
+  constexpr bool HAS_I8P32 = (DIM < 384);                // ... and the 32x32x32 logged build only where the 16x16x64 build does not exist
 #endif
   const bool defer = c->opt_i8_defer != 0 || c->i8_scales_signed;
-  const bool s16 = pipe && !w8 && !defer && c->opt_i8_mfma16 && DIM >= 512;
+  const bool s16 = pipe && !w8 && !defer && c->opt_i8_mfma16 && DIM >= 384;
   [[maybe_unused]] const bool s16w8 = pipe && w8 && !defer && c->opt_i8_mfma16 && DIM == 768;        // developer build: the 16x16x64 build on 8 waves (d = 768 only; measured equal to 4 waves)
   const uint32_t smask = static_cast<uint32_t>(c->opt_sync_every - 1), slead = static_cast<uint32_t>(c->opt_sync_lead);
   if (sync) {
@@ -828,6 +830,7 @@ nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq
     QT *= nb;                                      // the boot build is the 128-queries-per-workgroup kernel; same padded batch
     if (c->fdim == 768) return launch_boot_i8_dim<768>(c, s, n0, nq, QT, cap);
     if (c->fdim == 512) return launch_boot_i8_dim<512>(c, s, n0, nq, QT, cap);
+    if (c->fdim == 384) return launch_boot_i8_dim<384>(c, s, n0, nq, QT, cap);
     if (c->fdim == 256) return launch_boot_i8_dim<256>(c, s, n0, nq, QT, cap);
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 boot kernel: unsupported dim");
   }
@@ -856,12 +859,13 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
     if (c->fdim == 1536) return launch_filter_i8w_big_dim<1536>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (i8_two_stage(c)) {
 #define NVDB_I8W_DIM(D) if (c->fdim == D) return nb == 2 ? launch_filter_i8w_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap) : launch_filter_i8w_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap)
-      NVDB_I8W_DIM(768); NVDB_I8W_DIM(512); NVDB_I8W_DIM(256);
+      NVDB_I8W_DIM(768); NVDB_I8W_DIM(512); NVDB_I8W_DIM(384); NVDB_I8W_DIM(256);
 #undef NVDB_I8W_DIM
     }
 #ifdef NVDB_HIP_DEV
     if (c->fdim == 768) return launch_filter_i8_dim<768>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->fdim == 512) return launch_filter_i8_dim<512>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->fdim == 384) return launch_filter_i8_dim<384>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->fdim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
 #endif
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 filter kernel: unsupported dim");
@@ -1361,7 +1365,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "i8_mfma16") { c->opt_i8_mfma16 = value ? 1 : 0; }
 #else
   // kernel variants that lost their A/B (32x32x16 fp16 build for batches > 128, two-plane int8 kernel, filter_i8w_kernel at 64 queries
-  // per wave, 8-wave int8 build, 32x32x32 int8 build at d >= 512) live in libnvdb_hip_dev.so only; the product accepts their default values
+  // per wave, 8-wave int8 build, 32x32x32 int8 build at d >= 384) live in libnvdb_hip_dev.so only; the product accepts their default values
   else if (k == "mfma16" || k == "i8_wide" || k == "i8_pipe" || k == "i8_mfma16") { if (!value) return fail(c, NVDB_ERR_UNSUPPORTED, k + " = 0 selects a developer-build kernel variant (libnvdb_hip_dev.so)"); }
   else if (k == "i8_waves8") { if (value) return fail(c, NVDB_ERR_UNSUPPORTED, "i8_waves8 = 1 selects a developer-build kernel variant (libnvdb_hip_dev.so)"); }
 #endif

@@ -209,7 +209,7 @@ def test_filter_path_int8_matches_oracle(ctx, oracle, nq, k, d):
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[2][0], res[2][1], k, f"filter-i8/nq{nq}")
 
 
-@pytest.mark.parametrize("nq,k,d", [(300, 10, 768), (1024, 10, 768), (130, 64, 512), (200, 5, 256), (64, 10, 768), (1, 10, 768)])
+@pytest.mark.parametrize("nq,k,d", [(300, 10, 768), (1024, 10, 768), (130, 64, 512), (200, 5, 256), (64, 10, 768), (1, 10, 768), (300, 10, 384), (100, 64, 384)])
 def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx_dev, oracle, nq, k, d):
     """(developer library: it holds the builds the product's kernel is compared with)  int8 corpora run the two-stage kernel: hi plane always, lo plane only for tiles whose hi-plane value
     could reach the threshold (64 queries per wave for batches > 128, 32 below).  It must log exactly the survivors of the two-plane kernel, so ids, score
@@ -228,7 +228,7 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx_dev, oracle, nq, k, 
     # 0: two-plane kernel; 1: two-stage, software-pipelined build for batches > 128, first-stage survivors logged and finished
     # after the stream (the default); 2: two-stage, filter_i8w_kernel; 3: the pipelined build with the in-loop second stage
     # (deferred v_dot4 slots); 4: the same on 8 waves of 32 queries; 5: the product's default: the logged build on
-    # v_mfma_i32_16x16x64_i8 (d >= 512; d = 256 keeps the 32x32x32 build)
+    # v_mfma_i32_16x16x64_i8 (d >= 384; d = 256 keeps the 32x32x32 build)
     variants = ((0, 1, 0, 0, 0), (1, 1, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 0, 1, 0), (1, 1, 1, 1, 0), (1, 1, 0, 0, 1), (1, 1, 1, 0, 1))   # last: 16x16x64 on 8 waves (d = 768)
     for var, (wide, pipe, w8, defer, m16) in enumerate(variants):
         ctx.set_option("i8_wide", wide)
@@ -253,10 +253,36 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx_dev, oracle, nq, k, 
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[1][0], res[1][1], k, f"i8-wide/nq{nq}")
 
 
-@pytest.mark.parametrize("d,nq,k", [(384, 200, 10), (384, 48, 10), (100, 70, 5), (640, 300, 10)])
+@pytest.mark.parametrize("nq,k", [(1, 10), (48, 10), (128, 64), (200, 10), (1024, 10), (700, 3)])
+def test_int8_d384_native(ctx, oracle, nq, k):
+    """d = 384 is the reference's own data dimension (all-MiniLM-L6-v2, Performance.md): int8 rows of 384 bytes stream as they
+    are -- the LDS image of a tile uses the swizzle for row strides that are odd multiples of 128 bytes (kernels_filter.h,
+    swz_chunk).  Filter path == exact path == oracle for every batch regime (32 / 64 queries per wave, 1..4 query tiles)."""
+    n, d = 300000 + 37, 384
+    ctx.generate_corpus(SEED + 86, n, d, nvdb_amd.DT_I8)
+    base, scales = nvdb_amd.synth_corpus(SEED + 86, 0, n, d, nvdb_amd.DT_I8)
+    queries = nvdb_amd.synth_rows_f32(SEED + 87, 0, nq, d)
+    queries[0] = base[n - 1].astype(np.float32) * scales[n - 1]          # the last row (tail tile) is somebody's best match
+    if nq > 8:
+        queries[3] *= np.float32(512.0)
+        queries[5, 100:] = 0.0
+    res = {}
+    for path in (1, 2):
+        ctx.set_option("path", path)
+        res[path] = ctx.search_batch(queries, k)
+        st = ctx.stats()
+        assert st["path"] == path and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    ctx.set_option("path", 0)
+    assert res[2][0][0, 0] == n - 1
+    assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1].view(np.uint32), res[2][1].view(np.uint32))
+    sub = slice(0, min(nq, 16))
+    _check_against_oracle(oracle, base, po.DT_I8, scales, queries[sub], res[2][0][sub], res[2][1][sub], k, f"i8 d=384 nq={nq}")
+
+
+@pytest.mark.parametrize("d,nq,k", [(300, 200, 10), (320, 48, 10), (100, 70, 5), (640, 300, 10)])
 def test_int8_other_dims_through_the_zero_padded_shadow(ctx, oracle, d, nq, k):
-    """int8 corpora whose dim is not 256/512/768 (384 is the reference's own data dimension): the filter streams a
-    copy with rows zero-padded to the next multiple of 256 bytes; the rescore reads the original rows."""
+    """int8 corpora whose dim is not 256/384/512/768/1024/1280/1536: the filter streams a copy with rows zero-padded to the
+    next such dim (300 -> 384, 100 -> 256, 640 -> 768); the rescore reads the original rows."""
     n = 90000 + 3
     ctx.generate_corpus(SEED + 84, n, d, nvdb_amd.DT_I8)
     base, scales = nvdb_amd.synth_corpus(SEED + 84, 0, n, d, nvdb_amd.DT_I8)
@@ -321,10 +347,11 @@ def test_int8_big_dim_flat_queries_and_dense_blocks(ctx, oracle):
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries[:8], ids[:8], sc[:8], k, "i8 d=1536 flat")
 
 
-def test_int8_two_stage_kernel_with_a_negative_row_scale(ctx, oracle):
+@pytest.mark.parametrize("d", [256, 384])
+def test_int8_two_stage_kernel_with_a_negative_row_scale(ctx, oracle, d):
     """A negative row scale is never produced by the reference quantiser but is legal in the file format; both
     stages of the kernel are sign-agnostic (per-value products; |scale| in the lo-plane bound)."""
-    n, d, nq, k = 50000, 256, 160, 10
+    n, nq, k = 50000, 160, 10
     base, scales = nvdb_amd.synth_corpus(SEED + 82, 0, n, d, nvdb_amd.DT_I8)
     base, scales = base.copy(), scales.copy()
     base[100] = -base[100]; scales[100] = -scales[100]       # same dequantised row, negative scale

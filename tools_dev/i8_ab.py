@@ -6,7 +6,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd"))
 import numpy as np, torch, nvdb_amd
-n, d, B, K = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, 768, 1024, 10
+n, d, B, K = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, int(os.environ.get("I8_AB_DIM", "768")), 1024, 10
+VARIANTS = ((1, 0, 0, 1), (1, 1, 0, 1), (1, 0, 0, 0), (1, 1, 0, 1), (1, 0, 0, 1)) if d == 768 else ((1, 0, 0, 1), (1, 0, 0, 0), (1, 0, 0, 1), (1, 0, 0, 0))
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 ctx = nvdb_amd.HipContext(0, dev=True)     # the developer library holds the variants
@@ -15,7 +16,7 @@ q = torch.from_numpy(nvdb_amd.synth_rows_f32(20240614, 0, 4 * B, d)).to(dev)
 oi = torch.empty((B, K), dtype=torch.int64, device=dev); os_ = torch.empty((B, K), dtype=torch.float32, device=dev)
 ref = None
 for rnd in range(3):
-    for pipe, w8, defer, m16 in ((1, 0, 0, 1), (1, 1, 0, 1), (1, 0, 0, 0), (1, 1, 0, 1), (1, 0, 0, 1)):
+    for pipe, w8, defer, m16 in VARIANTS:
         ctx.set_option("i8_pipe", pipe)
         ctx.set_option("i8_mfma16", m16)
         ctx.set_option("i8_waves8", w8)

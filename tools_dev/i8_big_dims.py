@@ -9,10 +9,14 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 strm = torch.cuda.current_stream().cuda_stream
 K = 10
-for d, n in ((1536, 5_000_000), (1024, 5_000_000), (1280, 3_000_000), (1000, 3_000_000)):
+DIMS = ((1536, 5_000_000), (1024, 5_000_000), (1280, 3_000_000), (1000, 3_000_000))
+if len(sys.argv) > 1:                              # e.g. "384:10000000,512:10000000,256:10000000"
+    DIMS = tuple((int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.argv[1].split(","))
+BATCHES = tuple(int(x) for x in os.environ.get("I8_BATCHES", "1024,64").split(","))
+for d, n in DIMS:
     ctx = nvdb_amd.HipContext(0)
     ctx.generate_corpus(20240613, n, d, nvdb_amd.DT_I8)
-    for B in (1024, 64):
+    for B in BATCHES:
         q = torch.from_numpy(nvdb_amd.synth_rows_f32(20240614, 0, B, d)).to(dev)
         oi = torch.empty((B, K), dtype=torch.int64, device=dev); os_ = torch.empty((B, K), dtype=torch.float32, device=dev)
         res = {}
