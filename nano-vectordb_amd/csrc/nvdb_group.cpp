@@ -48,7 +48,7 @@ Rccl& rccl() {
       x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (x.handle) break;
     }
-    if (!x.handle) { x.why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return x; }
+    if (!x.handle) { const char* why = dlerror(); x.why = std::string("librccl not loadable: ") + (why ? why : "?"); return x; }   // (dlerror() clears itself: read it once)
 #define NVDB_SYM(field, sym)                                                         \
   x.field = reinterpret_cast<decltype(x.field)>(dlsym(x.handle, sym));               \
   if (!x.field) { x.why = std::string("librccl lacks ") + sym; x.handle = nullptr; return x; }
