@@ -19,7 +19,7 @@ for ci in range(cases):
     if tag == "i8" and dim > 768 and rs.rand() < 0.5: dim = 768
     n = int(rs.choice([1, 7, 33, 500, 2047, 2048, 2049, 4096, 10000, 33333, 70001, 150000]))
     nq = int(rs.choice([1, 2, 31, 32, 33, 64, 65, 128, 129, 200, 256, 257, 700, 1024, 1100]))
-    k = int(rs.choice([1, 3, 10, 10, 10, 33, 64]))
+    k = int(rs.choice([1, 3, 10, 10, 10, 33, 64, 64, 65, 100, 300, 1024, 1500]))      # > 64: wide k on the filter / the any-k path
     if n * dim > 150000 * 768: n = 150000 * 768 // dim
     ctx.generate_corpus(1000 + ci, n, dim, DT[tag])
     q = nvdb_amd.synth_rows_f32(5000 + ci, 0, nq, dim)
@@ -30,6 +30,8 @@ for ci in range(cases):
     if rs.rand() < 0.15: opts["mfma_boot"] = 0
     if rs.rand() < 0.15: opts["sibling_sync"] = 0
     if rs.rand() < 0.2: opts["xcd_balance"] = 0
+    if rs.rand() < 0.2: opts["exact_mfma"] = 0
+    if rs.rand() < 0.3: opts["exact_lds"] = int(rs.choice([0, 2]))
     if tag == "i8":
         if rs.rand() < 0.25: opts["i8_defer"] = 1
         if rs.rand() < 0.2: opts["i8_lo_bits"] = int(rs.choice([3, 5, 6]))
@@ -42,10 +44,10 @@ for ci in range(cases):
         base, scales = nvdb_amd.synth_corpus(1000 + ci, 0, n, dim, DT[tag])
         for qi in sorted(set([0, nq // 2, nq - 1])):
             oi, os_ = orc.flat_topk(base, {"f32": po.DT_F32, "f16": po.DT_F16, "i8": po.DT_I8}[tag], q[qi:qi + 1], k, scales)
-            ok = ok and np.array_equal(ei[qi], oi[0]) and np.array_equal(es[qi].view(np.uint32), osc.view(np.uint32)[0]) if False else ok and np.array_equal(ei[qi], oi[0]) and np.array_equal(es[qi].view(np.uint32), os_[0].view(np.uint32))
+            ok = ok and np.array_equal(ei[qi], oi[0]) and np.array_equal(es[qi].view(np.uint32), os_[0].view(np.uint32))
     except Exception as e:
         ok = False; st = {"error": str(e)}
-    for k_ in opts: ctx.set_option(k_, {"tile_permute": 1, "chunk_growth": 0, "mfma_boot": 1, "sibling_sync": 1, "xcd_balance": 1, "i8_defer": 0, "i8_lo_bits": 7, "boot_tiles": 0}[k_])
+    for k_ in opts: ctx.set_option(k_, {"tile_permute": 1, "chunk_growth": 0, "mfma_boot": 1, "sibling_sync": 1, "xcd_balance": 1, "i8_defer": 0, "i8_lo_bits": 7, "boot_tiles": 0, "exact_mfma": 1, "exact_lds": 1}[k_])
     ctx.set_option("path", 0)
     if not ok:
         fails += 1
