@@ -93,6 +93,7 @@ struct nvdb_hip_ctx {
 
   // grow-only workspace
   DevBuf q32, q16, qscale, qinv, ebound, slack, thr, cnt, overflow, cand, out_ids, out_scores, misc, hitlog, prog;
+  DevBuf hostblock;                                // host API, <= 1024 queries: [status words (= misc, aliased) | ids | scores] in one allocation, one D2H copy
   DevBuf rq, rcand, rout_ids, rout_dist;           // refine
   DevBuf xcdw;                                     // XCD balance: 8 speed weights + 16 accumulators (kernels_filter.h ScatterArgs::xcdw)
   int64_t opt_xcd_balance = 1;
@@ -149,6 +150,25 @@ nvdb_status ensure(nvdb_hip_ctx* c, DevBuf& b, size_t bytes) {
   size_t want = std::max<size_t>(bytes, 256);
   HIPCHK(c, hipMalloc(&b.p, want));
   b.bytes = want;
+  return NVDB_OK;
+}
+
+// The host API's result block: the 64 bytes of status words (c->misc points INTO the block from then on), ids, scores -- one
+// allocation, so that one copy brings down everything a search's caller waits for.  Growing it carries the status words
+// (the sticky ones outlive a search) over to the new allocation.
+nvdb_status ensure_hostblock(nvdb_hip_ctx* c, size_t out_bytes) {
+  const size_t need = 64 + out_bytes;
+  if (c->hostblock.p && c->hostblock.bytes >= need) return NVDB_OK;
+  HIPCHK(c, hipDeviceSynchronize());
+  void* np = nullptr;
+  const size_t want = std::max<size_t>(need + need / 2, static_cast<size_t>(1) << 20);
+  HIPCHK(c, hipMalloc(&np, want));
+  if (c->misc.p) HIPCHK(c, hipMemcpy(np, c->misc.p, 64, hipMemcpyDeviceToDevice));
+  else HIPCHK(c, hipMemset(np, 0, 64));
+  if (c->hostblock.p) HIPCHK(c, hipFree(c->hostblock.p));
+  else if (c->misc.p) HIPCHK(c, hipFree(c->misc.p));
+  c->hostblock.p = np; c->hostblock.bytes = want;
+  c->misc.p = np; c->misc.bytes = 64;
   return NVDB_OK;
 }
 
@@ -1054,9 +1074,10 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const uint32_t prog_words = PROG_SLOTS * static_cast<uint32_t>(c->num_cu) * 8u;
   if ((st = ensure(c, c->prog, static_cast<size_t>(prog_words) * 4))) return st;
   c->prog_slot = 0;
+  // (one query tile per stream has no siblings to keep in step: nothing to reset)
   init_search_kernel<<<(nq_pad + 255) / 256, 256, 0, s>>>(static_cast<uint32_t*>(c->cnt.p), static_cast<uint32_t*>(c->overflow.p),
                                                           static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->misc.p), nq_pad,
-                                                          static_cast<uint32_t*>(c->prog.p), prog_words);
+                                                          static_cast<uint32_t*>(c->prog.p), QT > 1 ? prog_words : 0u);
   HIPCHK(c, hipGetLastError());
 
   c->stats = nvdb_hip_scan_stats{};
@@ -1240,8 +1261,9 @@ void nvdb_hip_destroy(nvdb_hip_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_corpus(c);
+  if (c->hostblock.p) c->misc.p = nullptr;         // (misc lives inside the host API's result block)
   for (DevBuf* b : {&c->q32, &c->q16, &c->qscale, &c->qinv, &c->ebound, &c->slack, &c->thr, &c->cnt, &c->overflow, &c->cand,
-                    &c->out_ids, &c->out_scores, &c->misc, &c->hitlog, &c->prog, &c->qdelta, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist, &c->lk_scores, &c->lk_sel, &c->lk_hist, &c->lk_state, &c->xcdw})
+                    &c->out_ids, &c->out_scores, &c->misc, &c->hostblock, &c->hitlog, &c->prog, &c->qdelta, &c->rq, &c->rcand, &c->rout_ids, &c->rout_dist, &c->lk_scores, &c->lk_sel, &c->lk_hist, &c->lk_state, &c->xcdw})
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (auto& k : c->klaunch) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
@@ -1474,8 +1496,11 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
   hipStream_t s = c->stream;
   const size_t qbytes = static_cast<size_t>(nq) * c->dim * 4;
   if ((st = ensure(c, c->q32, qbytes + 8 * static_cast<size_t>(c->dim) * 4))) return st;
-  if ((st = ensure(c, c->out_ids, static_cast<size_t>(nq) * k * 8))) return st;
-  if ((st = ensure(c, c->out_scores, static_cast<size_t>(nq) * k * 4))) return st;
+  if (nq <= 1024) { if ((st = ensure_hostblock(c, static_cast<size_t>(nq) * k * 12))) return st; }
+  else {
+    if ((st = ensure(c, c->out_ids, static_cast<size_t>(nq) * k * 8))) return st;
+    if ((st = ensure(c, c->out_scores, static_cast<size_t>(nq) * k * 4))) return st;
+  }
   hipEvent_t e0 = get_event(c, 60), e1 = get_event(c, 61), e2 = get_event(c, 62), e3 = get_event(c, 63);
   c->stats_lazy = false;
   if (nq <= 1024) {
@@ -1501,14 +1526,19 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     else HIPCHK(c, hipMemcpyAsync(c->q32.p, queries, qbytes, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(e1, s));
     const float* dq = static_cast<const float*>(c->q32.p);
-    uint64_t* oi = static_cast<uint64_t*>(c->out_ids.p);
-    float* os = static_cast<float*>(c->out_scores.p);
+    uint64_t* oi = reinterpret_cast<uint64_t*>(static_cast<char*>(c->hostblock.p) + 64);
+    float* os = reinterpret_cast<float*>(static_cast<char*>(c->hostblock.p) + 64 + ob_ids);
     if ((st = search_core(c, s, dq, nq, k, oi, os, 0, timing != nullptr && c->opt_time_launches, 0, false))) return st;
     HIPCHK(c, hipEventRecord(e2, s));
     auto fetch = [&]() -> nvdb_status {
-      HIPCHK(c, hipMemcpyAsync(pin_status, c->misc.p, 32, hipMemcpyDeviceToHost, s));
-      HIPCHK(c, hipMemcpyAsync(stage_out ? static_cast<void*>(pin_ids) : static_cast<void*>(out_ids), oi, ob_ids, hipMemcpyDeviceToHost, s));
-      HIPCHK(c, hipMemcpyAsync(stage_out ? static_cast<void*>(pin_sc) : static_cast<void*>(out_scores), os, ob_sc, hipMemcpyDeviceToHost, s));
+      if (stage_out) {
+        // status words, ids and scores are adjacent on the device (ensure_hostblock) and in the staging buffer: ONE copy
+        HIPCHK(c, hipMemcpyAsync(pin, c->hostblock.p, 64 + ob_ids + ob_sc, hipMemcpyDeviceToHost, s));
+      } else {
+        HIPCHK(c, hipMemcpyAsync(pin_status, c->misc.p, 32, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(out_ids, oi, ob_ids, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(out_scores, os, ob_sc, hipMemcpyDeviceToHost, s));
+      }
       HIPCHK(c, hipEventRecord(e3, s));
       HIPCHK(c, hipStreamSynchronize(s));
       return NVDB_OK;
