@@ -145,3 +145,15 @@ def test_tile_permutation_is_a_bijection():
         assert img.max() == T - 1 and len(np.unique(img)) == T, T
         if T >= 1024:                                          # and it spreads: consecutive logical tiles are far apart
             assert np.median(np.abs(np.diff(img.astype(np.int64)))) > T // 8, T
+
+
+def test_makefile_targets_that_link_the_hip_library_depend_on_it():
+    """A parallel build of a fresh tree (what the driver's build check does after a clone: the .so files are not in
+    the history) must not link -lnvdb_hip before lib/libnvdb_hip.so exists: every rule whose recipe links it lists it."""
+    import re
+    mk = open(os.path.join(ROOT, "nano-vectordb_amd", "Makefile")).read()
+    rules = re.findall(r"^([^\s#:][^:\n]*):([^\n]*)\n((?:\t[^\n]*\n)+)", mk, flags=re.M)
+    linking = [(t.strip(), deps) for t, deps, recipe in rules if "-lnvdb_hip" in recipe]
+    assert len(linking) >= 5, linking
+    for target, deps in linking:
+        assert "lib/libnvdb_hip.so" in deps.split(), target
