@@ -4,6 +4,7 @@
 // status becomes std::runtime_error (reference convention, src/flat_index.cpp:17).
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "nvdb/topK.h"
@@ -22,10 +23,12 @@ class FlatIndexHIP {
   FlatIndexHIP(const FlatIndexHIP&) = delete;
   FlatIndexHIP& operator=(const FlatIndexHIP&) = delete;
 
+  // Like FlatIndex / FlatIndexOMP::search_topk_dot (const, callable from several threads at once): the device context
+  // behind it is single-owner, so concurrent callers take turns (one search at a time per index; batch to use the GPU).
   std::vector<SearchResult> search_topk_dot(const float* q, uint32_t k) const;
   // nq queries [nq][dim]; result [nq][min(k,N)] row-major, best first
   std::vector<SearchResult> search_topk_dot_batch(const float* queries, uint32_t nq, uint32_t k) const;
-  double last_kernel_ms() const { return last_kernel_ms_; }
+  double last_kernel_ms() const { return last_kernel_ms_; }       // of the calling thread's last search only when callers do not overlap
   nvdb_hip_ctx* context() const { return ctx_; }
 
  private:
@@ -33,6 +36,7 @@ class FlatIndexHIP {
   uint64_t n_ = 0;
   uint32_t dim_ = 0;
   mutable double last_kernel_ms_ = 0.0;
+  mutable std::mutex mu_;                          // one search at a time on the context
 };
 
 // Row-sharded flat index over several GPUs of one node, driven from ONE process (the reference has no multi-GPU path):
@@ -60,6 +64,7 @@ class FlatIndexHIPSharded {
   uint64_t n_ = 0;
   uint32_t dim_ = 0;
   mutable unsigned fallbacks_ = 0;
+  mutable std::mutex mu_;                          // one search at a time on the group
 };
 
 }  // namespace nvdb

@@ -39,8 +39,11 @@ std::vector<SearchResult> FlatIndexHIP::search_topk_dot_batch(const float* queri
   std::vector<float> sc(static_cast<size_t>(nq) * k);
   uint32_t keff = 0;
   nvdb_hip_timing t;
-  check(ctx_, nvdb_hip_search_batch(ctx_, queries, nq, k, ids.data(), sc.data(), &keff, &t));
-  last_kernel_ms_ = t.kernel_ms;
+  {
+    std::lock_guard<std::mutex> own(mu_);          // (the error text lives in the context: read it under the lock too)
+    check(ctx_, nvdb_hip_search_batch(ctx_, queries, nq, k, ids.data(), sc.data(), &keff, &t));
+    last_kernel_ms_ = t.kernel_ms;
+  }
   std::vector<SearchResult> out(static_cast<size_t>(nq) * keff);
   for (uint32_t q = 0; q < nq; ++q)
     for (uint32_t j = 0; j < keff; ++j) out[static_cast<size_t>(q) * keff + j] = SearchResult{ids[static_cast<size_t>(q) * k + j], sc[static_cast<size_t>(q) * k + j]};
@@ -85,9 +88,12 @@ std::vector<SearchResult> FlatIndexHIPSharded::search_topk_dot_batch(const float
   std::vector<float> sc(per);
   uint32_t keff = 0;
   nvdb_hip_group_stats gs{};
-  if (nvdb_hip_group_search_batch(grp_, queries, nq, k, ids.data(), sc.data(), &keff, &gs) != NVDB_OK)
-    throw std::runtime_error(std::string(nvdb_hip_group_last_error(grp_)));
-  fallbacks_ += gs.host_merge_fallbacks;
+  {
+    std::lock_guard<std::mutex> own(mu_);
+    if (nvdb_hip_group_search_batch(grp_, queries, nq, k, ids.data(), sc.data(), &keff, &gs) != NVDB_OK)
+      throw std::runtime_error(std::string(nvdb_hip_group_last_error(grp_)));
+    fallbacks_ += gs.host_merge_fallbacks;
+  }
   std::vector<SearchResult> out(static_cast<size_t>(nq) * keff);
   for (uint32_t q = 0; q < nq; ++q)
     for (uint32_t j = 0; j < keff; ++j) out[static_cast<size_t>(q) * keff + j] = SearchResult{ids[static_cast<size_t>(q) * k + j], sc[static_cast<size_t>(q) * k + j]};

@@ -7,11 +7,14 @@
 #include <cstdint>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "nvdb/cpu_refine.h"
 #include "nvdb/f16_scalar.h"
+#include "nvdb/flat_index_hip.h"
 #include "nvdb/simd_dot.h"
 #include "nvdb/to_f32_row.h"
 #include "nvdb/vector_dataset.h"
@@ -56,6 +59,39 @@ int nvdb_host_refine_topk_l2(void* h, const float* q, const int64_t* cand, int c
       if (out_dist) out_dist[j] = j < dist.size() ? dist[j] : __builtin_huge_valf();
     }
     return static_cast<int>(ids.size());
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+// FlatIndexHIP / FlatIndexHIPSharded::search_topk_dot from `threads` host threads at once (const entry points, like the
+// reference's FlatIndex): thread t takes the queries t, t + threads, ...; out_ids / out_scores [nq][k] (padded with
+// UINT64_MAX / -inf).  devices == nullptr: one GPU (device 0); else a row-sharded index over n_devices devices.
+int nvdb_host_hip_concurrent_search(void* h, const float* queries, uint32_t nq, uint32_t k, int threads, const int* devices,
+                                    uint32_t n_devices, uint64_t* out_ids, float* out_scores) {
+  try {
+    const auto* ds = static_cast<nvdb::VectorDataset*>(h);
+    std::unique_ptr<nvdb::FlatIndexHIP> one;
+    std::unique_ptr<nvdb::FlatIndexHIPSharded> many;
+    if (devices) many.reset(new nvdb::FlatIndexHIPSharded(ds, std::vector<int>(devices, devices + n_devices)));
+    else one.reset(new nvdb::FlatIndexHIP(ds));
+    const uint32_t dim = ds->dim();
+    std::vector<std::string> errs(static_cast<size_t>(threads));
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t)
+      th.emplace_back([&, t] {
+        try {
+          for (uint32_t q = static_cast<uint32_t>(t); q < nq; q += static_cast<uint32_t>(threads)) {
+            const float* qp = queries + static_cast<size_t>(q) * dim;
+            const std::vector<nvdb::SearchResult> r = one ? one->search_topk_dot(qp, k) : many->search_topk_dot(qp, k);
+            for (uint32_t j = 0; j < k; ++j) {
+              out_ids[static_cast<size_t>(q) * k + j] = j < r.size() ? r[j].id : ~0ull;
+              out_scores[static_cast<size_t>(q) * k + j] = j < r.size() ? r[j].score : -__builtin_huge_valf();
+            }
+          }
+        } catch (const std::exception& e) { errs[static_cast<size_t>(t)] = e.what(); }
+      });
+    for (auto& x : th) x.join();
+    for (const auto& e : errs) if (!e.empty()) { g_err = e; return -1; }
+    return 0;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 

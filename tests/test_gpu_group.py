@@ -159,3 +159,34 @@ def test_bench_rccl_branch_with_one_rank():
     assert "backend nccl" in line["exchange"] and "world 1" in line["exchange"]
     assert line["parity"].startswith("ok") and line["scan"]["path"] == 2 and line["scan"]["bound_violations"] == 0
     assert line["n_gpus"] == 1 and line["value"] > 0
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+def test_index_objects_take_concurrent_callers(tmp_path, oracle, devices):
+    """nvdb::FlatIndexHIP / FlatIndexHIPSharded::search_topk_dot are const like the reference's FlatIndex, whose callers may
+    overlap (threading); the device context is single-owner, so the classes serialise.  Six host threads, one
+    query at a time each, against the batched answer."""
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "nano-vectordb_amd", "lib", "libnvdb_host_capi.so"))
+    L.nvdb_host_dataset_open.restype = C.c_void_p
+    L.nvdb_host_dataset_open.argtypes = [C.c_char_p]
+    L.nvdb_host_dataset_close.argtypes = [C.c_void_p]
+    L.nvdb_host_last_error.restype = C.c_char_p
+    L.nvdb_host_hip_concurrent_search.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    n, d, nq, k = 150_000, 384, 96, 10
+    base = oracle.f32_to_f16(nvdb_amd.synth_rows_f32(SEED + 60, 0, n, d))
+    queries = np.ascontiguousarray(nvdb_amd.synth_rows_f32(SEED + 61, 0, nq, d))
+    p = str(tmp_path / "b16.vecbin")
+    po.write_vecbin(p, base, po.DT_F16)
+    c = nvdb_amd.HipContext(0)
+    c.upload_corpus(base, nvdb_amd.DT_F16)
+    want_i, want_s = c.search_batch(queries, k)
+    c.close()
+    h = L.nvdb_host_dataset_open(p.encode())
+    assert h, L.nvdb_host_last_error()
+    ids = np.zeros((nq, k), np.uint64); sc = np.zeros((nq, k), np.float32)
+    dev = (C.c_int * len(devices))(*devices) if devices else None
+    rc = L.nvdb_host_hip_concurrent_search(h, queries.ctypes.data, nq, k, 6, dev, len(devices) if devices else 0, ids.ctypes.data, sc.ctypes.data)
+    L.nvdb_host_dataset_close(h)
+    assert rc == 0, L.nvdb_host_last_error()
+    assert np.array_equal(ids, want_i) and np.array_equal(sc.view(np.uint32), want_s.view(np.uint32))
