@@ -431,4 +431,7 @@ __global__ __launch_bounds__(64 * REFINE3_WAVES) void refine_l2_rows_kernel(cons
 // per row -- the reference's four accumulator chains cannot be split further -- a 3 KB row costs one lane 192 dependent pair
 // steps while half the wave idles (8 rows x 3 KB fill the same 24 KB slot as 16 x 1.5 KB), and a 16-row slot no longer leaves
 // room for six waves per CU; v2's lane-per-row layout keeps all 64 lanes busy on 64 rows.
+// Two re-shapings of v2 itself were measured too and dropped (profiles/r03_refine_v2_variants.txt): 512-byte chunks on two waves
+// (half as many, longer requests: 5.9 / 8.7 ms against 4.4 / 6.5 at d = 1024 / 1536) and three buffers on three waves (two chunks
+// ahead: 5.1 / 7.4 ms) -- what v2 needs is its four waves, not longer or deeper requests.
 }  // namespace nvdbhip
