@@ -205,7 +205,7 @@ bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 38
 constexpr uint32_t F16_FILTER_MAX_DIM = 3072;
 constexpr uint32_t I8W_TILE_ROWS = 64;                // rows per tile of the int8 two-stage kernel (two 32-row blocks)
 constexpr uint32_t PAD_ROWS = 64;                     // zero rows every library-owned corpus / shadow is padded with: the largest tile
-bool i8_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 1024 || dim == 1280 || dim == 1536; }   // int8 rows: stride % 128 == 0 (swz_chunk)
+bool i8_filter_dim(uint32_t dim) { return dim % 128 == 0 && dim >= 256 && dim <= 1536; }   // int8 rows: every multiple of 128 bytes from 256 (swz_chunk's two families)
 constexpr uint32_t I8_FILTER_MAX_DIM = 1536;
 bool refine3_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256; }   // fp16 dims of the whole-row refine kernel
 
@@ -850,6 +850,7 @@ nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq
     QT *= nb;                                      // the boot build is the 128-queries-per-workgroup kernel; same padded batch
     if (c->fdim == 768) return launch_boot_i8_dim<768>(c, s, n0, nq, QT, cap);
     if (c->fdim == 512) return launch_boot_i8_dim<512>(c, s, n0, nq, QT, cap);
+    if (c->fdim == 640) return launch_boot_i8_dim<640>(c, s, n0, nq, QT, cap);
     if (c->fdim == 384) return launch_boot_i8_dim<384>(c, s, n0, nq, QT, cap);
     if (c->fdim == 256) return launch_boot_i8_dim<256>(c, s, n0, nq, QT, cap);
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 boot kernel: unsupported dim");
@@ -874,17 +875,21 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
   const uint32_t nb = filter_nb(c, nq);
   if (c->dtype == NVDB_DTYPE_I8) {
     const uint32_t nq_pad = QT * 128u * nb;
+    if (c->fdim == 896) return launch_filter_i8w_big_dim<896>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->fdim == 1024) return launch_filter_i8w_big_dim<1024>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->fdim == 1152) return launch_filter_i8w_big_dim<1152>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->fdim == 1408) return launch_filter_i8w_big_dim<1408>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->fdim == 1280) return launch_filter_i8w_big_dim<1280>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->fdim == 1536) return launch_filter_i8w_big_dim<1536>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (i8_two_stage(c)) {
 #define NVDB_I8W_DIM(D) if (c->fdim == D) return nb == 2 ? launch_filter_i8w_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap) : launch_filter_i8w_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap)
-      NVDB_I8W_DIM(768); NVDB_I8W_DIM(512); NVDB_I8W_DIM(384); NVDB_I8W_DIM(256);
+      NVDB_I8W_DIM(768); NVDB_I8W_DIM(640); NVDB_I8W_DIM(512); NVDB_I8W_DIM(384); NVDB_I8W_DIM(256);
 #undef NVDB_I8W_DIM
     }
 #ifdef NVDB_HIP_DEV
     if (c->fdim == 768) return launch_filter_i8_dim<768>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->fdim == 512) return launch_filter_i8_dim<512>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
+    if (c->fdim == 640) return launch_filter_i8_dim<640>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->fdim == 384) return launch_filter_i8_dim<384>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
     if (c->fdim == 256) return launch_filter_i8_dim<256>(c, s, row_lo, row_hi, nq, QT, nq_pad, cap);
 #endif

@@ -209,7 +209,7 @@ def test_filter_path_int8_matches_oracle(ctx, oracle, nq, k, d):
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[2][0], res[2][1], k, f"filter-i8/nq{nq}")
 
 
-@pytest.mark.parametrize("nq,k,d", [(300, 10, 768), (1024, 10, 768), (130, 64, 512), (200, 5, 256), (64, 10, 768), (1, 10, 768), (300, 10, 384), (100, 64, 384)])
+@pytest.mark.parametrize("nq,k,d", [(300, 10, 768), (1024, 10, 768), (130, 64, 512), (200, 5, 256), (64, 10, 768), (1, 10, 768), (300, 10, 384), (100, 64, 384), (260, 10, 640)])
 def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx_dev, oracle, nq, k, d):
     """(developer library: it holds the builds the product's kernel is compared with)  int8 corpora run the two-stage kernel: hi plane always, lo plane only for tiles whose hi-plane value
     could reach the threshold (64 queries per wave for batches > 128, 32 below).  It must log exactly the survivors of the two-plane kernel, so ids, score
@@ -253,12 +253,12 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx_dev, oracle, nq, k, 
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[1][0], res[1][1], k, f"i8-wide/nq{nq}")
 
 
-@pytest.mark.parametrize("nq,k", [(1, 10), (48, 10), (128, 64), (200, 10), (1024, 10), (700, 3)])
-def test_int8_d384_native(ctx, oracle, nq, k):
+@pytest.mark.parametrize("nq,k,d", [(1, 10, 384), (48, 10, 384), (128, 64, 384), (200, 10, 384), (1024, 10, 384), (700, 3, 384), (100, 10, 640), (520, 10, 640)])
+def test_int8_d384_native(ctx, oracle, nq, k, d):
     """d = 384 is the reference's own data dimension (all-MiniLM-L6-v2, Performance.md): int8 rows of 384 bytes stream as they
     are -- the LDS image of a tile uses the swizzle for row strides that are odd multiples of 128 bytes (kernels_filter.h,
     swz_chunk).  Filter path == exact path == oracle for every batch regime (32 / 64 queries per wave, 1..4 query tiles)."""
-    n, d = 300000 + 37, 384
+    n = 300000 + 37                                              # (d = 640: the same swizzle family, five 128-byte groups per row)
     ctx.generate_corpus(SEED + 86, n, d, nvdb_amd.DT_I8)
     base, scales = nvdb_amd.synth_corpus(SEED + 86, 0, n, d, nvdb_amd.DT_I8)
     queries = nvdb_amd.synth_rows_f32(SEED + 87, 0, nq, d)
@@ -276,13 +276,13 @@ def test_int8_d384_native(ctx, oracle, nq, k):
     assert res[2][0][0, 0] == n - 1
     assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1].view(np.uint32), res[2][1].view(np.uint32))
     sub = slice(0, min(nq, 16))
-    _check_against_oracle(oracle, base, po.DT_I8, scales, queries[sub], res[2][0][sub], res[2][1][sub], k, f"i8 d=384 nq={nq}")
+    _check_against_oracle(oracle, base, po.DT_I8, scales, queries[sub], res[2][0][sub], res[2][1][sub], k, f"i8 d={d} nq={nq}")
 
 
-@pytest.mark.parametrize("d,nq,k", [(300, 200, 10), (320, 48, 10), (100, 70, 5), (640, 300, 10)])
+@pytest.mark.parametrize("d,nq,k", [(300, 200, 10), (320, 48, 10), (100, 70, 5), (600, 300, 10)])
 def test_int8_other_dims_through_the_zero_padded_shadow(ctx, oracle, d, nq, k):
-    """int8 corpora whose dim is not 256/384/512/768/1024/1280/1536: the filter streams a copy with rows zero-padded to the
-    next such dim (300 -> 384, 100 -> 256, 640 -> 768); the rescore reads the original rows."""
+    """int8 corpora whose dim is not a multiple of 128 in [256, 1536]: the filter streams a copy with rows zero-padded to the
+    next one (300 -> 384, 100 -> 256, 600 -> 640); the rescore reads the original rows."""
     n = 90000 + 3
     ctx.generate_corpus(SEED + 84, n, d, nvdb_amd.DT_I8)
     base, scales = nvdb_amd.synth_corpus(SEED + 84, 0, n, d, nvdb_amd.DT_I8)
@@ -299,10 +299,11 @@ def test_int8_other_dims_through_the_zero_padded_shadow(ctx, oracle, d, nq, k):
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[2][0], res[2][1], k, f"i8-pad/d{d}")
 
 
-@pytest.mark.parametrize("d,nq,k", [(1536, 300, 10), (1024, 64, 10), (1280, 130, 5), (1000, 200, 10), (1100, 33, 64), (1536, 1, 10), (1400, 1024, 10)])
+@pytest.mark.parametrize("d,nq,k", [(1536, 300, 10), (1024, 64, 10), (1280, 130, 5), (1000, 200, 10), (1100, 33, 64), (1536, 1, 10), (1400, 1024, 10), (896, 150, 10), (1152, 64, 10), (1408, 300, 5)])
 def test_int8_dims_up_to_1536_on_integer_mfma(ctx, oracle, d, nq, k):
     """768 < dim <= 1536 (the reference takes any dim, src/simd_dot.cpp:160-213): the two-stage int8 kernel on 32-row tiles
-    with 32 queries per wave, K-step count up to 48; dims that are not 1024 / 1280 / 1536 stream a zero-padded copy.
+    with 32 queries per wave, K-step count up to 48; every multiple of 128 streams as it is (896 / 1152 / 1408: the LDS swizzle for
+    odd multiples of 128 bytes), other dims stream a zero-padded copy.
     Results come from the original rows either way."""
     n = 70_000 + 13
     base32 = nvdb_amd.synth_rows_f32(SEED + 140 + d, 0, n, d)
