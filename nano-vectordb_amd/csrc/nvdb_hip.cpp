@@ -201,7 +201,7 @@ void free_corpus(nvdb_hip_ctx* c) {
 // (16 queries per wave, a tile streamed as two half-K stages)
 constexpr uint32_t PROG_SLOTS = 16;   // filter launches per search whose rendezvous counters the init kernel pre-clears
 
-bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128 || dim == 1024 || dim == 1536 || dim == 2048 || dim == 3072; }
+bool f16_filter_dim(uint32_t dim) { return dim == 768 || dim == 640 || dim == 512 || dim == 384 || dim == 256 || dim == 128 || dim == 896 || dim == 1024 || dim == 1152 || dim == 1280 || dim == 1408 || dim == 1536 || dim == 2048 || dim == 2560 || dim == 3072; }
 constexpr uint32_t F16_FILTER_MAX_DIM = 3072;
 constexpr uint32_t I8W_TILE_ROWS = 64;                // rows per tile of the int8 two-stage kernel (two 32-row blocks)
 constexpr uint32_t PAD_ROWS = 64;                     // zero rows every library-owned corpus / shadow is padded with: the largest tile
@@ -603,7 +603,7 @@ nvdb_status launch_filter_k_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo,
                           static_cast<const float*>(c->qinv.p), static_cast<Hit*>(c->hitlog.p), scatter_args(c, cap, 16), prog, \
                           static_cast<uint32_t>(c->opt_sync_every - 1), static_cast<uint32_t>(c->opt_sync_lead));               \
   }
-  if (sync && c->opt_waves8) {
+  if constexpr (DIM % 256 == 0) if (sync && c->opt_waves8) {     // (a tile's DIM / 32 pieces split over 8 waves)
     // two waves per SIMD: 8 waves x 16 queries (DIM/8 <= 192 registers of fragments per wave)
     if ((st = ensure(c, c->hitlog, static_cast<size_t>(nwg) * 8 * FILTER_LOGCAP * sizeof(Hit)))) return st;
     const void* f8 = reinterpret_cast<const void*>(filter_f16_m16_kernel<DIM, 4, true, false, 0, 1, 1, 8>);
@@ -856,7 +856,7 @@ nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 boot kernel: unsupported dim");
   }
 #define NVDB_BOOT_DIM(D) if (c->fdim == D) return nb == 1 ? launch_boot_dim<D, 1>(c, s, n0, nq, QT, cap) : launch_boot_dim<D, 2>(c, s, n0, nq, QT, cap)
-  NVDB_BOOT_DIM(768); NVDB_BOOT_DIM(512); NVDB_BOOT_DIM(384); NVDB_BOOT_DIM(256); NVDB_BOOT_DIM(128);
+  NVDB_BOOT_DIM(768); NVDB_BOOT_DIM(640); NVDB_BOOT_DIM(512); NVDB_BOOT_DIM(384); NVDB_BOOT_DIM(256); NVDB_BOOT_DIM(128);
 #undef NVDB_BOOT_DIM
   return fail(c, NVDB_ERR_UNSUPPORTED, "boot kernel: unsupported dim");
 }
@@ -896,11 +896,16 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
     return fail(c, NVDB_ERR_UNSUPPORTED, "int8 filter kernel: unsupported dim");
   }
   if (c->fdim == 2048) return launch_filter_k2_dim<2048>(c, s, row_lo, row_hi, nq, QT, cap);
+  if (c->fdim == 2560) return launch_filter_k2_dim<2560>(c, s, row_lo, row_hi, nq, QT, cap);
   if (c->fdim == 3072) return launch_filter_k2_dim<3072>(c, s, row_lo, row_hi, nq, QT, cap);
+  if (c->fdim == 896) return launch_filter_k_dim<896>(c, s, row_lo, row_hi, nq, QT, cap);
   if (c->fdim == 1024) return launch_filter_k_dim<1024>(c, s, row_lo, row_hi, nq, QT, cap);
+  if (c->fdim == 1152) return launch_filter_k_dim<1152>(c, s, row_lo, row_hi, nq, QT, cap);
+  if (c->fdim == 1280) return launch_filter_k_dim<1280>(c, s, row_lo, row_hi, nq, QT, cap);
+  if (c->fdim == 1408) return launch_filter_k_dim<1408>(c, s, row_lo, row_hi, nq, QT, cap);
   if (c->fdim == 1536) return launch_filter_k_dim<1536>(c, s, row_lo, row_hi, nq, QT, cap);
 #define NVDB_FILTER_DIM(D) if (c->fdim == D) return nb == 1 ? launch_filter_dim<D, 1>(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_dim<D, 2>(c, s, row_lo, row_hi, nq, QT, cap)
-  NVDB_FILTER_DIM(768); NVDB_FILTER_DIM(512); NVDB_FILTER_DIM(384); NVDB_FILTER_DIM(256); NVDB_FILTER_DIM(128);
+  NVDB_FILTER_DIM(768); NVDB_FILTER_DIM(640); NVDB_FILTER_DIM(512); NVDB_FILTER_DIM(384); NVDB_FILTER_DIM(256); NVDB_FILTER_DIM(128);
 #undef NVDB_FILTER_DIM
   return fail(c, NVDB_ERR_UNSUPPORTED, "filter kernel: unsupported dim");
 }

@@ -452,7 +452,7 @@ def test_filter_path_with_exact_duplicates(ctx, oracle):
     ctx.set_option("path", 0)
 
 
-@pytest.mark.parametrize("d,nq", [(384, 40), (128, 200), (256, 33), (512, 150)])
+@pytest.mark.parametrize("d,nq", [(384, 40), (128, 200), (256, 33), (512, 150), (640, 300), (640, 40)])
 def test_filter_and_exact_paths_agree_on_other_dims(ctx, oracle, d, nq):
     n, k = 80000, 10                                         # 384 is the reference's own data dimension
     ctx.generate_corpus(SEED + 2, n, d, nvdb_amd.DT_F16)
@@ -491,7 +491,8 @@ def test_filter_path_on_zero_padded_shadow_for_odd_dims(ctx, oracle, tag, d, nq)
 
 
 @pytest.mark.parametrize("tag,d,nq", [("f16", 1536, 300), ("f16", 1024, 64), ("f16", 1000, 130), ("f32", 1536, 40), ("f16", 1280, 33),
-                                      ("f16", 3072, 200), ("f16", 2048, 70), ("f16", 2500, 130), ("f32", 3072, 20), ("f16", 1600, 600)])
+                                      ("f16", 3072, 200), ("f16", 2048, 70), ("f16", 2500, 130), ("f32", 3072, 20), ("f16", 1600, 600),
+                                      ("f16", 896, 300), ("f16", 1152, 64), ("f16", 1408, 1024), ("f16", 2560, 100), ("f32", 1280, 150)])
 def test_filter_path_for_dims_up_to_1536(ctx, oracle, tag, d, nq):
     """768 < dim <= 1536: the 16-row-tile build of the fp16 kernel (32 queries per wave); 1536 < dim <= 3072: the K-split
     build (16 queries per wave, a tile streamed as two half-K stages); other dims through the zero-padded shadow.  Same
