@@ -295,7 +295,7 @@ nvdb_status launch_scan_exact_qg(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo
 }
 
 // dims the fp32-MFMA exact kernels are instantiated for (dim % 32 == 0: no scalar tail; 16 queries x dim floats in registers)
-bool exact_mfma_dim(uint32_t dim) { return dim == 768 || dim == 512 || dim == 384 || dim == 256 || dim == 128; }
+bool exact_mfma_dim(uint32_t dim) { return dim == 768 || dim == 640 || dim == 512 || dim == 384 || dim == 256 || dim == 128; }
 
 // The exact scan on the fp32 matrix cores (kernels_exact_mfma.h).  A query receives at most P * nslice * k list entries, nslice = 4 / (16-query
 // blocks of its group of 64, rounded up to 1, 2 or 4).
@@ -326,7 +326,7 @@ nvdb_status launch_scan_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_
       q0 = gy * 64; lds_done = true;                                                                                               \
     }                                                                                                                              \
   }
-  NVDB_SCAN_LDS(768) NVDB_SCAN_LDS(512) NVDB_SCAN_LDS(384) NVDB_SCAN_LDS(256) NVDB_SCAN_LDS(128)
+  NVDB_SCAN_LDS(768) NVDB_SCAN_LDS(640) NVDB_SCAN_LDS(512) NVDB_SCAN_LDS(384) NVDB_SCAN_LDS(256) NVDB_SCAN_LDS(128)
 #undef NVDB_SCAN_LDS
   (void)lds_done;
   if (q0 >= nq) return NVDB_OK;
@@ -345,6 +345,7 @@ nvdb_status launch_scan_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_
 #define NVDB_SCAN_MFMA(D) scan_exact_mfma_kernel<DT, D><<<grid, 256, 0, s>>>(c->rows, c->scales, row_lo, row_hi, qr, nr, k, thr_r, cand + static_cast<size_t>(q0) * cap, cnt + q0, cap, ovf + q0)
   switch (c->dim) {
     case 768: NVDB_SCAN_MFMA(768); break;
+    case 640: NVDB_SCAN_MFMA(640); break;
     case 512: NVDB_SCAN_MFMA(512); break;
     case 384: NVDB_SCAN_MFMA(384); break;
     case 256: NVDB_SCAN_MFMA(256); break;
@@ -948,7 +949,7 @@ nvdb_status launch_scores_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, const float
       q0 = gy * 64;                                                                                                                \
     }                                                                                                                              \
   }
-#define NVDB_SC_LDS_DT(DT) NVDB_SC_LDS(DT, 768) NVDB_SC_LDS(DT, 512) NVDB_SC_LDS(DT, 384) NVDB_SC_LDS(DT, 256) NVDB_SC_LDS(DT, 128)
+#define NVDB_SC_LDS_DT(DT) NVDB_SC_LDS(DT, 768) NVDB_SC_LDS(DT, 640) NVDB_SC_LDS(DT, 512) NVDB_SC_LDS(DT, 384) NVDB_SC_LDS(DT, 256) NVDB_SC_LDS(DT, 128)
   if (c->dtype == NVDB_DTYPE_F32) { NVDB_SC_LDS_DT(DT_F32) } else if (c->dtype == NVDB_DTYPE_F16) { NVDB_SC_LDS_DT(DT_F16) } else { NVDB_SC_LDS_DT(DT_I8) }
 #undef NVDB_SC_LDS_DT
 #undef NVDB_SC_LDS
@@ -964,6 +965,7 @@ nvdb_status launch_scores_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, const float
 #define NVDB_SC_MFMA_DT(DT)                                                                                       \
   switch (c->dim) {                                                                                              \
     case 768: NVDB_SC_MFMA(DT, 768); break;                                                                      \
+    case 640: NVDB_SC_MFMA(DT, 640); break;                                                                      \
     case 512: NVDB_SC_MFMA(DT, 512); break;                                                                      \
     case 384: NVDB_SC_MFMA(DT, 384); break;                                                                      \
     case 256: NVDB_SC_MFMA(DT, 256); break;                                                                      \

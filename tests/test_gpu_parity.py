@@ -1212,7 +1212,7 @@ def test_int8_corpus_with_a_huge_row_scale_takes_the_unbiased_build(oracle):
 
 
 @pytest.mark.parametrize("tag", ["f16", "f32", "i8"])
-@pytest.mark.parametrize("d,nq", [(768, 64), (768, 9), (768, 33), (384, 100), (128, 17), (512, 48), (256, 130), (128, 64), (768, 200)])
+@pytest.mark.parametrize("d,nq", [(768, 64), (768, 9), (768, 33), (384, 100), (128, 17), (512, 48), (256, 130), (128, 64), (768, 200), (640, 70), (640, 10)])
 def test_exact_scores_on_the_fp32_matrix_cores(oracle, tag, d, nq):
     """Path 1 with more than 8 queries on dims that are whole MFMA K-steps runs on v_mfma_f32_16x16x4_f32 (eight accumulator
     tiles = the reference's eight stride-8 fma chains, kernels_exact_mfma.h): ids and score BITS must equal the VALU kernels'
