@@ -15,7 +15,7 @@ DT = {"f32": nvdb_amd.DT_F32, "f16": nvdb_amd.DT_F16, "i8": nvdb_amd.DT_I8}
 t0 = time.time(); fails = 0
 for ci in range(cases):
     tag = rs.choice(["f16", "f16", "i8", "i8", "f32"])
-    dim = int(rs.choice([8, 24, 64, 100, 128, 200, 256, 384, 500, 512, 640, 768, 768, 768, 1000, 1024, 1536, 1600, 2048, 3072, 3100]))
+    dim = int(rs.choice([8, 24, 64, 100, 128, 200, 256, 384, 500, 512, 640, 768, 768, 768, 896, 1000, 1024, 1152, 1280, 1408, 1536, 1600, 2048, 2560, 3072, 3100]))
     if tag == "i8" and dim > 768 and rs.rand() < 0.5: dim = 768
     n = int(rs.choice([1, 7, 33, 500, 2047, 2048, 2049, 4096, 10000, 33333, 70001, 150000]))
     nq = int(rs.choice([1, 2, 31, 32, 33, 64, 65, 128, 129, 200, 256, 257, 700, 1024, 1100]))
