@@ -177,4 +177,16 @@ __global__ __launch_bounds__(256) void emit_kernel(const unsigned long long* __r
   }
 }
 
+// the same keys into the filter path's candidate lists instead (exact bootstrap of a wide-k search, search_core): entry j of
+// query q = (exact score, row inside the shard); cnt[q] = k
+__global__ __launch_bounds__(256) void seed_lists_kernel(const unsigned long long* __restrict__ sel, uint32_t K2, const float* __restrict__ scores, uint64_t ld,
+                                                         uint32_t k, Cand* __restrict__ cand, uint32_t cap, uint32_t* __restrict__ cnt) {
+  const uint32_t q = blockIdx.y;
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= k) return;
+  const uint32_t row = ~static_cast<uint32_t>(sel[static_cast<uint64_t>(q) * K2 + j]);
+  cand[static_cast<uint64_t>(q) * cap + j] = Cand{scores[static_cast<uint64_t>(q) * ld + row], row};
+  if (j == 0) cnt[q] = k;
+}
+
 }  // namespace nvdbhip

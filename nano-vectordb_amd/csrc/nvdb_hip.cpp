@@ -913,8 +913,7 @@ nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint3
 
 // ---- any k (kernels_largek.h): exact scores of a query sub-batch -> radix select of the k-th key -> sort -> emit ----------
 template <int QG>
-nvdb_status launch_scores_exact_qg(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uint32_t nq, float* out, uint64_t ld) {
-  const uint32_t n = static_cast<uint32_t>(c->n);
+nvdb_status launch_scores_exact_qg(nvdb_hip_ctx* c, hipStream_t s, const float* q32, uint32_t nq, float* out, uint64_t ld, uint32_t n) {
   const dim3 grid(std::min<uint32_t>((n + 255u) / 256u, 8u * static_cast<uint32_t>(c->num_cu)), (nq + QG - 1) / QG);
   const bool al = aligned_rows(c->dtype, c->dim);
   const size_t lds = static_cast<size_t>(QG) * ((c->dim + 3u) & ~3u) * 4;
@@ -978,9 +977,12 @@ nvdb_status launch_scores_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, const float
   return NVDB_OK;
 }
 
-nvdb_status search_largek(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint32_t nq, uint32_t k, uint64_t* dev_out_ids, float* dev_out_scores) {
-  const uint32_t n = static_cast<uint32_t>(c->n);
-  const uint32_t k_eff = static_cast<uint32_t>(std::min<uint64_t>(k, c->n));
+// seed_cand != nullptr: only the rows [0, n_rows) and the result goes into the filter path's candidate lists (exact bootstrap of a
+// wide-k search on dims without an MFMA bootstrap build) instead of the output arrays
+nvdb_status search_largek(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint32_t nq, uint32_t k, uint64_t* dev_out_ids, float* dev_out_scores,
+                          uint32_t n_rows = 0, Cand* seed_cand = nullptr, uint32_t* seed_cnt = nullptr, uint32_t seed_cap = 0) {
+  const uint32_t n = seed_cand ? n_rows : static_cast<uint32_t>(c->n);
+  const uint32_t k_eff = static_cast<uint32_t>(std::min<uint64_t>(k, n));
   const uint64_t ld = (static_cast<uint64_t>(n) + 63u) & ~63ull;
   uint32_t K2 = 2;
   while (K2 < k_eff) K2 <<= 1;
@@ -1017,12 +1019,12 @@ nvdb_status search_largek(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, ui
     const uint32_t b = std::min(QB, nq - q0);
     const float* q = dev_q + static_cast<size_t>(q0) * c->dim;
     radix_init_kernel<<<b, 256, 0, s>>>(rst, hist, b, k_eff);
-    if (c->opt_exact_mfma && b > 8 && exact_mfma_dim(c->dim) && n >= 64u * EXACT_MFMA_ROWS) st = launch_scores_exact_mfma(c, s, q, b, scores, ld);
+    if (!seed_cand && c->opt_exact_mfma && b > 8 && exact_mfma_dim(c->dim) && n >= 64u * EXACT_MFMA_ROWS) st = launch_scores_exact_mfma(c, s, q, b, scores, ld);
     else switch (QG) {
-      case 8: st = launch_scores_exact_qg<8>(c, s, q, b, scores, ld); break;
-      case 4: st = launch_scores_exact_qg<4>(c, s, q, b, scores, ld); break;
-      case 2: st = launch_scores_exact_qg<2>(c, s, q, b, scores, ld); break;
-      default: st = launch_scores_exact_qg<1>(c, s, q, b, scores, ld); break;
+      case 8: st = launch_scores_exact_qg<8>(c, s, q, b, scores, ld, n); break;
+      case 4: st = launch_scores_exact_qg<4>(c, s, q, b, scores, ld, n); break;
+      case 2: st = launch_scores_exact_qg<2>(c, s, q, b, scores, ld, n); break;
+      default: st = launch_scores_exact_qg<1>(c, s, q, b, scores, ld, n); break;
     }
     if (st) return st;
     const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>((n + 255u) / 256u, (8u * static_cast<uint32_t>(c->num_cu) + b - 1) / b));
@@ -1036,11 +1038,13 @@ nvdb_status search_largek(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, ui
       for (uint32_t size = 2; size <= K2; size <<= 1)
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1)
           bitonic_global_step_kernel<<<dim3((K2 / 2 + 255) / 256, b), 256, 0, s>>>(sel, K2, size, stride);
-    emit_kernel<<<dim3((k + 255) / 256, b), 256, 0, s>>>(sel, K2, scores, ld, k_eff, k, c->row_base,
-                                                        reinterpret_cast<unsigned long long*>(dev_out_ids) + static_cast<size_t>(q0) * k,
-                                                        dev_out_scores + static_cast<size_t>(q0) * k);
+    if (seed_cand) seed_lists_kernel<<<dim3((k_eff + 255) / 256, b), 256, 0, s>>>(sel, K2, scores, ld, k_eff, seed_cand + static_cast<size_t>(q0) * seed_cap, seed_cap, seed_cnt + q0);
+    else emit_kernel<<<dim3((k + 255) / 256, b), 256, 0, s>>>(sel, K2, scores, ld, k_eff, k, c->row_base,
+                                                             reinterpret_cast<unsigned long long*>(dev_out_ids) + static_cast<size_t>(q0) * k,
+                                                             dev_out_scores + static_cast<size_t>(q0) * k);
     HIPCHK(c, hipGetLastError());
   }
+  if (seed_cand) return NVDB_OK;
   c->stats.chunks = (nq + QB - 1) / QB;
   c->stats.rows_scanned = c->n;
   return NVDB_OK;
@@ -1068,8 +1072,12 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // 8k tile maxima and chunks small enough that k * (growth - 1) new survivors + the k kept ones + the error band fit.
   // Anything else beyond the wavefront lists' 64 entries takes the any-k path.
   const bool k_wide = k_eff > WAVE_KMAX;
-  const bool wide_on_filter = k_wide && path == 2 && force_path != 1 && k_eff <= FILTER_KMAX && c->opt_mfma_boot &&
-                              c->fdim <= 768 && c->n >= 2ull * FILTER_ROWS * 8 * k_eff;
+  // dims whose kernels have no MFMA bootstrap build (768 < dim): an EXACT bootstrap over the first 8k tiles' rows on the any-k
+  // machinery (score matrix of the sample -> radix select -> the k best seed the lists), then the filter streams the rest
+  const bool wide_exact_boot = k_wide && path == 2 && force_path != 1 && k_eff <= FILTER_KMAX && c->fdim > 768 &&
+                               c->n >= 4ull * FILTER_ROWS * 8 * k_eff;
+  const bool wide_on_filter = wide_exact_boot || (k_wide && path == 2 && force_path != 1 && k_eff <= FILTER_KMAX && c->opt_mfma_boot &&
+                              c->fdim <= 768 && c->n >= 2ull * FILTER_ROWS * 8 * k_eff);
   if (wide_on_filter) cap = SELECT_MAX_CAP;
   // queries per filter workgroup: 256 / 128, or 64 on the K-split build (dims > 1536)
   const uint32_t QPB = (c->dtype != NVDB_DTYPE_I8 && c->fdim > 1536) ? 64u : 128u * filter_nb(c, nq);
@@ -1158,7 +1166,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   const bool mfma_boot = c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
                          boot_rows / FILTER_ROWS <= cap &&
                          c->fdim <= 768;    // no bootstrap build of the 16-row-tile fp16 kernel / the 32-query int8 kernel: exact bootstrap chunk
-  if (k_wide && !mfma_boot) {
+  if (k_wide && !mfma_boot && !wide_exact_boot) {
     // 64 < k on the filter path needs the MFMA bootstrap (the exact bootstrap chunk's wavefront lists hold 64 entries);
     // e.g. option boot_tiles larger than the corpus: the any-k path takes the search instead
     c->stats.path = 3; c->last_filter = false;
@@ -1174,8 +1182,10 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     size = static_cast<uint64_t>(boot_rows) * growth;
   } else {
     // bootstrap chunk [0,r) on the exact kernel; r is a multiple of the 32-row MFMA tile
-    r = std::min<uint32_t>(n_al, (static_cast<uint32_t>(c->opt_chunk0) + tile_rows - 1) / tile_rows * tile_rows);
+    r = std::min<uint32_t>(n_al, (static_cast<uint32_t>(k_wide ? FILTER_ROWS * 8u * k_eff : c->opt_chunk0) + tile_rows - 1) / tile_rows * tile_rows);
     if (r > n) r = n / tile_rows * tile_rows;
+    if (k_wide) { if ((st = search_largek(c, s, dev_q, nq, k_eff, nullptr, nullptr, r, static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap))) return st; }
+    else
     if ((st = launch_scan_exact(c, s, 0, r, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
     if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
     size = static_cast<uint64_t>(r) * (growth - 1);
