@@ -555,7 +555,7 @@ def main():
         sec = kt["ms"] * 1e-3
         ach = kt["flops"] / sec / 1e12
         peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_I8_TOPS
-        kname = (("filter_f16_m16_kernel<768> (8 waves x 32 queries)" if B > 128 else "filter_f16_kernel<768,1>") if args.dtype == "f16" else ("filter_i8s_kernel<768> (two-stage build on v_mfma_i32_16x16x64_i8)" if B > 128 else "filter_i8w_kernel<768,1>"))
+        kname = (("filter_f16_m16_kernel<768> (8 waves x 32 queries)" if B > 128 else "filter_f16_kernel<768,1>") if args.dtype == "f16" else ("filter_i8s_kernel<768> (two-stage build on v_mfma_i32_16x16x64_i8)" if B > 128 else ("filter_i8s_kernel<768> on 8 waves of 32 queries" if B > 8 else "filter_i8w_kernel<768,1>")))
         gbps = kt["bytes"] / sec / 1e9
         # ridge point: intensity = 2*B*dim flop per row / row bytes  vs  peak flop / peak bytes
         hbm_bound = (2.0 * B * D / bpr) < (peak * 1e12 / (PEAK_HBM_GBPS * 1e9))

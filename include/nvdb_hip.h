@@ -213,7 +213,7 @@ nvdb_status nvdb_hip_group_search_batch(nvdb_hip_group* group, const float* quer
  * matrix cores), "exact_lds", "i8_defer", "i8_lo_bits", "boot_tiles", "xcd_balance", "rescore8", "refine_v2", "refine_pinned" (reference CUDA_PINNED:
  * pinned host staging in nvdb_hip_refine_l2_topk), "largek_budget_mb" (HBM for the any-k path's score matrix), "time_kernels" (1: start /
  * stop events attached to every launch of the dominant kernel, read by nvdb_hip_collect_kernel_times), "time_launches" (the same for one host-API
- * call with a timing struct -> stats.filter_kernel_ms).  "mfma16", "i8_wide", "i8_pipe", "i8_waves8", "i8_mfma16" select kernel
+ * call with a timing struct -> stats.filter_kernel_ms).  "mfma16", "i8_wide", "i8_pipe", "i8_waves8", "i8_mfma16", "i8_small8" select kernel
  * variants that exist in libnvdb_hip_dev.so only: the product accepts their default values (1, 1, 1, 0, 1) and returns
  * NVDB_ERR_UNSUPPORTED for the others.  Unknown key -> NVDB_ERR_INVALID. */
 nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* ctx, const char* key, int64_t value);

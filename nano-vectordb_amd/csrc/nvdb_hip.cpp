@@ -99,6 +99,7 @@ struct nvdb_hip_ctx {
   int64_t opt_xcd_balance = 1;
   int64_t opt_i8_lo_bits = 7;                      // int8: bits of a quantised query's lo plane (ScatterArgs::lo_bits)
   int64_t opt_boot_tiles = 0;                      // threshold bootstrap over this many 32-row tile maxima (0: max(64, 8k))
+  int64_t opt_i8_small8 = 1;                       // int8 d = 768, batches <= 128: 1 = the 8-wave 16x16x64 logged build, 0 = filter_i8w_kernel<768, 1> (developer library)
   int64_t dbg_rows = 0;                            // developer build: rows the stamped launches of nvdb_hip_debug_clock_i8 cover (0: the corpus)
   DevBuf lk_scores, lk_sel, lk_hist, lk_state;     // any-k path (kernels_largek.h): score matrix of a query sub-batch, selected keys, radix state
   int64_t opt_refine_pinned = 0;                   // refine host call: stage queries / candidates / results through pinned host buffers (reference CUDA_PINNED)
@@ -752,6 +753,16 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   constexpr bool HAS_I8P32 = (DIM < 384);                // ... and the 32x32x32 logged build only where the 16x16x64 build does not exist
 #endif
   const bool defer = c->opt_i8_defer != 0 || c->i8_scales_signed;
+  // batches <= 128 at d = 768: the 16x16x64 logged build on 8 waves of 32 queries (waves without queries only load): its first-stage
+  // test rides in the MFMA shadow, so four busy waves stay inside the tile time the HBM stream allows (+6.5 % at batch 128,
+  // +2.4 % at 64 over filter_i8w_kernel<768, 1>, profiles/r03_i8_small_batch_ab.txt); signed / huge scales keep the in-loop build
+  if constexpr (NB == 1 && DIM == 768) {
+    if (c->opt_i8_small8 && !defer && QT == 1 && nq > 8) {      // (a handful of queries: equal within noise, the old kernel stays)
+      NVDB_I8S_LAUNCH_W(false, nullptr, 0u, 0u, 8)
+      HIPCHK(c, hipGetLastError());
+      return NVDB_OK;
+    }
+  }
   const bool s16 = pipe && !w8 && !defer && c->opt_i8_mfma16 && DIM >= 384;
   [[maybe_unused]] const bool s16w8 = pipe && w8 && !defer && c->opt_i8_mfma16 && DIM == 768;        // developer build: the 16x16x64 build on 8 waves (d = 768 only; measured equal to 4 waves)
   const uint32_t smask = static_cast<uint32_t>(c->opt_sync_every - 1), slead = static_cast<uint32_t>(c->opt_sync_lead);
@@ -1407,10 +1418,11 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "i8_pipe") { c->opt_i8_pipe = value ? 1 : 0; }
   else if (k == "i8_waves8") { c->opt_i8_waves8 = value ? 1 : 0; }
   else if (k == "i8_mfma16") { c->opt_i8_mfma16 = value ? 1 : 0; }
+  else if (k == "i8_small8") { c->opt_i8_small8 = value ? 1 : 0; }
 #else
   // kernel variants that lost their A/B (32x32x16 fp16 build for batches > 128, two-plane int8 kernel, filter_i8w_kernel at 64 queries
   // per wave, 8-wave int8 build, 32x32x32 int8 build at d >= 384) live in libnvdb_hip_dev.so only; the product accepts their default values
-  else if (k == "mfma16" || k == "i8_wide" || k == "i8_pipe" || k == "i8_mfma16") { if (!value) return fail(c, NVDB_ERR_UNSUPPORTED, k + " = 0 selects a developer-build kernel variant (libnvdb_hip_dev.so)"); }
+  else if (k == "mfma16" || k == "i8_wide" || k == "i8_pipe" || k == "i8_mfma16" || k == "i8_small8") { if (!value) return fail(c, NVDB_ERR_UNSUPPORTED, k + " = 0 selects a developer-build kernel variant (libnvdb_hip_dev.so)"); }
   else if (k == "i8_waves8") { if (value) return fail(c, NVDB_ERR_UNSUPPORTED, "i8_waves8 = 1 selects a developer-build kernel variant (libnvdb_hip_dev.so)"); }
 #endif
 
