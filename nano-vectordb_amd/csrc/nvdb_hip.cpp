@@ -99,7 +99,7 @@ struct nvdb_hip_ctx {
   int64_t opt_xcd_balance = 1;
   int64_t opt_i8_lo_bits = 7;                      // int8: bits of a quantised query's lo plane (ScatterArgs::lo_bits)
   int64_t opt_boot_tiles = 0;                      // threshold bootstrap over this many 32-row tile maxima (0: max(64, 8k))
-  int64_t opt_i8_small8 = 1;                       // int8 d = 768, batches <= 128: 1 = the 8-wave 16x16x64 logged build, 0 = filter_i8w_kernel<768, 1> (developer library)
+  int64_t opt_i8_small8 = 1;                       // int8 d = 512 / 768, batches <= 128: 1 = the 8-wave 16x16x64 logged build, 0 = filter_i8w_kernel<768, 1> (developer library)
   int64_t dbg_rows = 0;                            // developer build: rows the stamped launches of nvdb_hip_debug_clock_i8 cover (0: the corpus)
   DevBuf lk_scores, lk_sel, lk_hist, lk_state;     // any-k path (kernels_largek.h): score matrix of a query sub-batch, selected keys, radix state
   int64_t opt_refine_pinned = 0;                   // refine host call: stage queries / candidates / results through pinned host buffers (reference CUDA_PINNED)
@@ -730,7 +730,7 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
 #define NVDB_I8S_LAUNCH(SYNCV, PROG, MASK, LEAD) NVDB_I8S_LAUNCH_W(SYNCV, PROG, MASK, LEAD, 4)
 #define NVDB_I8S_LAUNCH_W(SYNCV, PROG, MASK, LEAD, WPBV)                                                                          \
   {                                                                                                                             \
-    if constexpr (DIM >= 384 && (WPBV == 4 || DIM == 768)) {                                                                    \
+    if constexpr (DIM >= 384 && (WPBV == 4 || DIM == 768 || DIM == 512)) {                                                                    \
       constexpr size_t ldss = static_cast<size_t>(3) * (I8W_TILE_ROWS * DIM + WPBV * 256);                                      \
       const void* fn = reinterpret_cast<const void*>(filter_i8s_kernel<DIM, SYNCV, false, 6, 0, WPBV>);                         \
       if (!c->lds_attr_set.count(fn)) {                                                                                         \
@@ -753,10 +753,10 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   constexpr bool HAS_I8P32 = (DIM < 384);                // ... and the 32x32x32 logged build only where the 16x16x64 build does not exist
 #endif
   const bool defer = c->opt_i8_defer != 0 || c->i8_scales_signed;
-  // batches <= 128 at d = 768: the 16x16x64 logged build on 8 waves of 32 queries (waves without queries only load): its first-stage
+  // batches <= 128 at d = 512 / 768: the 16x16x64 logged build on 8 waves of 32 queries (waves without queries only load): its first-stage
   // test rides in the MFMA shadow, so four busy waves stay inside the tile time the HBM stream allows (+6.5 % at batch 128,
   // +2.4 % at 64 over filter_i8w_kernel<768, 1>, profiles/r03_i8_small_batch_ab.txt); signed / huge scales keep the in-loop build
-  if constexpr (NB == 1 && DIM == 768) {
+  if constexpr (NB == 1 && (DIM == 768 || DIM == 512)) {
     if (c->opt_i8_small8 && !defer && QT == 1 && nq > 8) {      // (a handful of queries: equal within noise, the old kernel stays)
       NVDB_I8S_LAUNCH_W(false, nullptr, 0u, 0u, 8)
       HIPCHK(c, hipGetLastError());

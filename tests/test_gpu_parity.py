@@ -209,7 +209,7 @@ def test_filter_path_int8_matches_oracle(ctx, oracle, nq, k, d):
     _check_against_oracle(oracle, base, po.DT_I8, scales, queries, res[2][0], res[2][1], k, f"filter-i8/nq{nq}")
 
 
-@pytest.mark.parametrize("nq,k,d", [(300, 10, 768), (1024, 10, 768), (130, 64, 512), (200, 5, 256), (64, 10, 768), (1, 10, 768), (300, 10, 384), (100, 64, 384), (260, 10, 640), (128, 10, 768), (33, 64, 768)])
+@pytest.mark.parametrize("nq,k,d", [(300, 10, 768), (1024, 10, 768), (130, 64, 512), (200, 5, 256), (64, 10, 768), (1, 10, 768), (300, 10, 384), (100, 64, 384), (260, 10, 640), (128, 10, 768), (33, 64, 768), (100, 10, 512)])
 def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx_dev, oracle, nq, k, d):
     """(developer library: it holds the builds the product's kernel is compared with)  int8 corpora run the two-stage kernel: hi plane always, lo plane only for tiles whose hi-plane value
     could reach the threshold (64 queries per wave for batches > 128, 32 below).  It must log exactly the survivors of the two-plane kernel, so ids, score
@@ -244,9 +244,9 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx_dev, oracle, nq, k, 
     ctx.set_option("i8_waves8", 0)
     ctx.set_option("i8_defer", 0)
     ctx.set_option("i8_mfma16", 1)
-    if 8 < nq <= 128 and d == 768:
+    if 8 < nq <= 128 and d in (512, 768):
         # batches <= 128 run the 16x16x64 logged build on 8 waves (the variants above that do not defer all took it):
-        # against filter_i8w_kernel<768, 1>, the kernel these batches ran before
+        # against filter_i8w_kernel<DIM, 1>, the kernel these batches ran before
         ctx.set_option("i8_small8", 0)
         old = ctx.search_batch(queries, k)
         st_old = ctx.stats()

@@ -7,7 +7,7 @@ import numpy as np, torch, nvdb_amd
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 strm = torch.cuda.current_stream().cuda_stream
-n, d, K = 10_000_000, 768, 10
+n, d, K = 10_000_000, int(os.environ.get("AB_DIM", "768")), 10
 ctx = nvdb_amd.HipContext(0, dev=True)
 ctx.generate_corpus(20240613, n, d, nvdb_amd.DT_I8)
 for B in (128, 100, 64, 32, 8, 1):
