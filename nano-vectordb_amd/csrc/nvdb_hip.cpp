@@ -756,6 +756,13 @@ nvdb_status launch_filter_i8w_dim(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_l
   // batches <= 128 at d = 512 / 768: the 16x16x64 logged build on 8 waves of 32 queries (waves without queries only load): its first-stage
   // test rides in the MFMA shadow, so four busy waves stay inside the tile time the HBM stream allows (+6.5 % at batch 128,
   // +2.4 % at 64 over filter_i8w_kernel<768, 1>, profiles/r03_i8_small_batch_ab.txt); signed / huge scales keep the in-loop build
+  if constexpr (NB == 1 && DIM == 384) {             // d = 384 has no 8-wave schedule: 64 < batch <= 128 on the 4-wave build, two waves without queries (+4 % at 128; equal at 64)
+    if (c->opt_i8_small8 && !defer && QT == 1 && nq > 64) {
+      NVDB_I8S_LAUNCH(false, nullptr, 0u, 0u)
+      HIPCHK(c, hipGetLastError());
+      return NVDB_OK;
+    }
+  }
   if constexpr (NB == 1 && (DIM == 768 || DIM == 512)) {
     if (c->opt_i8_small8 && !defer && QT == 1 && nq > 8) {      // (a handful of queries: equal within noise, the old kernel stays)
       NVDB_I8S_LAUNCH_W(false, nullptr, 0u, 0u, 8)

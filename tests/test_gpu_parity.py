@@ -244,7 +244,7 @@ def test_int8_two_stage_kernel_matches_two_plane_kernel(ctx_dev, oracle, nq, k, 
     ctx.set_option("i8_waves8", 0)
     ctx.set_option("i8_defer", 0)
     ctx.set_option("i8_mfma16", 1)
-    if 8 < nq <= 128 and d in (512, 768):
+    if (8 < nq <= 128 and d in (512, 768)) or (64 < nq <= 128 and d == 384):
         # batches <= 128 run the 16x16x64 logged build on 8 waves (the variants above that do not defer all took it):
         # against filter_i8w_kernel<DIM, 1>, the kernel these batches ran before
         ctx.set_option("i8_small8", 0)
