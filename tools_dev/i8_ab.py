@@ -6,7 +6,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd"))
 import numpy as np, torch, nvdb_amd
-n, d, B, K = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, int(os.environ.get("I8_AB_DIM", "768")), 1024, 10
+n, d, B, K = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, int(os.environ.get("I8_AB_DIM", "768")), int(os.environ.get("I8_AB_BATCH", "1024")), 10
 VARIANTS = ((1, 0, 0, 1), (1, 1, 0, 1), (1, 0, 0, 0), (1, 1, 0, 1), (1, 0, 0, 1)) if d == 768 else ((1, 0, 0, 1), (1, 0, 0, 0), (1, 0, 0, 1), (1, 0, 0, 0))
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
