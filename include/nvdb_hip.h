@@ -152,8 +152,9 @@ nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* ctx, nvdb_hip_scan_stats* stats)
 nvdb_status nvdb_hip_get_stats(nvdb_hip_ctx* ctx, nvdb_hip_scan_stats* stats);
 
 /* Merge per-shard top-k lists (e.g. after an RCCL all-gather): in[s][nq][k] -> out[nq][k] with
- * the same (score desc, id asc) order.  Device buffers, enqueued on hip_stream.  nshards*k <= 4096 (the lists of one
- * query are ranked in LDS); beyond that NVDB_ERR_UNSUPPORTED -- use nvdb_merge_topk_host (the device group does). */
+ * the same (score desc, id asc) order.  Device buffers, enqueued on hip_stream.  Any k the flat path accepts (the reference
+ * bounds k by N only, src/flat_index.cpp:24): up to nshards*k = 4096 the lists of one query are ranked in LDS; longer ones are
+ * merged by binary searches and must arrive sorted best-first with their padding (id ~0, -inf) last, as every search emits them. */
 nvdb_status nvdb_hip_merge_topk_dev(nvdb_hip_ctx* ctx, const uint64_t* dev_ids, const float* dev_scores,
                                     uint32_t nshards, uint32_t nq, uint32_t k, uint64_t* dev_out_ids,
                                     float* dev_out_scores, void* hip_stream);
@@ -177,7 +178,9 @@ nvdb_status nvdb_merge_topk_host(const uint64_t* ids, const float* scores, uint3
  * for bit).  RCCL is bound with dlopen at group creation; when it cannot serve the list (a device named twice, RCCL
  * absent, NVDB_GROUP_NO_RCCL=1) the exchange is G peer copies into devices[0] and the same merge kernel.
  * A shard whose self-check trips (list overflow, non-finite query) sends the sub-batch through the per-shard host API
- * (which retries / falls back by itself) and a host-side merge; so does nshards*k > 4096 (merge kernel's LDS).
+ * (which retries / falls back by itself) and a host-side merge.
+ * NVDB_GROUP_RCCL_LIB=<path> (read at group creation) binds the six RCCL entry points from another library instead: the tests
+ * drive the RCCL branch with several ranks on one device through a loopback stand-in (tests/loopback_rccl).
  * One process per GPU (bench.py, torch.distributed) uses nvdb_hip_search_batch_dev + the caller's all-gather +
  * nvdb_hip_merge_topk_strided_dev instead -- same kernels, same packed layout.
  * ------------------------------------------------------------------------------------------- */

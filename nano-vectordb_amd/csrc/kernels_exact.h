@@ -640,4 +640,38 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(
   }
 }
 
+// The same merge for nshards * k beyond what fits the LDS of merge_topk_kernel (4096 entries): every shard's list arrives sorted
+// best-first by (score desc, id asc) with its padding (id ~0, -inf) last, so an entry's position in the merged list is its own
+// position plus, for every other shard, the number of that shard's entries that come before it -- one binary search per shard
+// straight out of the gathered buffer (L2).  Any k the flat path accepts (the reference bounds k by N only, flat_index.cpp:24).
+// Total order = merge_topk_kernel's: (score desc, id asc, flat position asc); ids are global, hence distinct except for padding.
+__global__ __launch_bounds__(256) void merge_topk_sorted_kernel(
+    const unsigned long long* __restrict__ ids, const float* __restrict__ scores, uint32_t nshards, uint32_t nq,
+    uint32_t k, unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, size_t stride_ids_bytes,
+    size_t stride_scores_bytes) {
+  const uint32_t q = blockIdx.y;
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nshards * k) return;
+  const uint32_t sh = i / k, j = i % k;
+  const uint64_t qoff = static_cast<uint64_t>(q) * k;
+  const float si = reinterpret_cast<const float*>(reinterpret_cast<const char*>(scores) + sh * stride_scores_bytes)[qoff + j];
+  const unsigned long long ii = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(ids) + sh * stride_ids_bytes)[qoff + j];
+  uint32_t rank = j;
+  for (uint32_t t = 0; t < nshards && rank < k; ++t) {
+    if (t == sh) continue;
+    const float* ts = reinterpret_cast<const float*>(reinterpret_cast<const char*>(scores) + t * stride_scores_bytes) + qoff;
+    const unsigned long long* ti = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(ids) + t * stride_ids_bytes) + qoff;
+    uint32_t lo = 0, hi = k;                         // first position of shard t that does NOT come before my entry
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      const float sj = ts[mid];
+      const unsigned long long ij = ti[mid];
+      const bool before = (sj > si) || (sj == si && (ij < ii || (ij == ii && t < sh)));
+      if (before) lo = mid + 1; else hi = mid;
+    }
+    rank += lo;
+  }
+  if (rank < k) { out_ids[qoff + rank] = ii; out_scores[qoff + rank] = si; }
+}
+
 }  // namespace nvdbhip

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <thread>
@@ -38,30 +40,41 @@ struct Rccl {
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string why;
+  bool override_lib = false;                    // loaded from NVDB_GROUP_RCCL_LIB (a stand-in that also serves repeated devices)
   bool ok() const { return handle != nullptr; }
 };
 
-Rccl& rccl() {
-  static Rccl r = [] {
-    Rccl x;
-    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
-      x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (x.handle) break;
-    }
-    if (!x.handle) { const char* why = dlerror(); x.why = std::string("librccl not loadable: ") + (why ? why : "?"); return x; }   // (dlerror() clears itself: read it once)
+// One table per library path.  Default: the librccl already in the process (PyTorch bundles one), else /opt/rocm's.
+// NVDB_GROUP_RCCL_LIB=<path>, read when a group is created, names another library with the same six entry points; the tests
+// use it to drive THIS file's RCCL branch with several ranks on one device through a loopback stand-in
+// (tests/loopback_rccl: it serves a device listed more than once, which RCCL itself refuses).
+Rccl& rccl(const std::string& override_path) {
+  static std::mutex mu;
+  static std::map<std::string, Rccl> tables;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tables.find(override_path);
+  if (it != tables.end()) return it->second;
+  Rccl x;
+  x.override_lib = !override_path.empty();
+  const std::vector<std::string> names = x.override_lib ? std::vector<std::string>{override_path}
+                                                        : std::vector<std::string>{"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+  for (const std::string& name : names) {
+    x.handle = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (x.handle) break;
+  }
+  auto done = [&](Rccl& r) -> Rccl& { return tables.emplace(override_path, r).first->second; };
+  if (!x.handle) { const char* why = dlerror(); x.why = std::string("librccl not loadable: ") + (why ? why : "?"); return done(x); }   // (dlerror() clears itself: read it once)
 #define NVDB_SYM(field, sym)                                                         \
   x.field = reinterpret_cast<decltype(x.field)>(dlsym(x.handle, sym));               \
-  if (!x.field) { x.why = std::string("librccl lacks ") + sym; x.handle = nullptr; return x; }
-    NVDB_SYM(CommInitAll, "ncclCommInitAll")
-    NVDB_SYM(CommDestroy, "ncclCommDestroy")
-    NVDB_SYM(GroupStart, "ncclGroupStart")
-    NVDB_SYM(GroupEnd, "ncclGroupEnd")
-    NVDB_SYM(AllGather, "ncclAllGather")
-    NVDB_SYM(GetErrorString, "ncclGetErrorString")
+  if (!x.field) { x.why = std::string("librccl lacks ") + sym; x.handle = nullptr; return done(x); }
+  NVDB_SYM(CommInitAll, "ncclCommInitAll")
+  NVDB_SYM(CommDestroy, "ncclCommDestroy")
+  NVDB_SYM(GroupStart, "ncclGroupStart")
+  NVDB_SYM(GroupEnd, "ncclGroupEnd")
+  NVDB_SYM(AllGather, "ncclAllGather")
+  NVDB_SYM(GetErrorString, "ncclGetErrorString")
 #undef NVDB_SYM
-    return x;
-  }();
-  return r;
+  return done(x);
 }
 
 std::string g_group_create_err;
@@ -74,6 +87,7 @@ struct nvdb_hip_group {
   std::vector<hipStream_t> stream;
   std::vector<hipEvent_t> done;                 // per device: its search (+ its copy in peer-copy mode) has been enqueued up to here
   std::vector<ncclComm_t> comm;                 // empty in peer-copy mode
+  Rccl* R = nullptr;                            // the library the communicators came from
   std::vector<void*> dq, packed, gathered;      // per device: queries, [ids | scores] of its shard, all shards' packed blocks
   void* merged = nullptr;                       // device 0: [ids | scores] of the merged lists
   void* pinned = nullptr;                       // host staging of the merged lists
@@ -152,6 +166,8 @@ nvdb_status search_sub_batch(nvdb_hip_group* g, const float* queries, uint32_t n
   std::vector<std::string> errs(G);
   auto shard = [&](size_t i) {
     hipError_t e = hipSetDevice(g->devices[i]);
+    // the 8 rows after the batch are zeros on every call (a smaller batch after a larger one would otherwise leave stale queries there)
+    if (e == hipSuccess) e = hipMemsetAsync(static_cast<char*>(g->dq[i]) + qb, 0, 8 * static_cast<size_t>(g->dim) * 4, g->stream[i]);
     if (e == hipSuccess) e = hipMemcpyAsync(g->dq[i], queries, qb, hipMemcpyHostToDevice, g->stream[i]);
     if (e != hipSuccess) { sts[i] = NVDB_ERR_HIP; errs[i] = hipGetErrorString(e); return; }
     char* p = static_cast<char*>(g->packed[i]);
@@ -174,7 +190,7 @@ nvdb_status search_sub_batch(nvdb_hip_group* g, const float* queries, uint32_t n
   for (size_t i = 0; i < G; ++i) if (sts[i]) return gfail(g, sts[i], "shard " + std::to_string(i) + ": " + errs[i]);
   // 2. the exchange
   if (g->use_rccl) {
-    Rccl& R = rccl();
+    Rccl& R = *g->R;
     ncclResult_t r = R.GroupStart();
     for (size_t i = 0; i < G && r == ncclSuccess; ++i)
       r = R.AllGather(g->packed[i], g->gathered[i], pb, ncclUint8, g->comm[i], g->stream[i]);
@@ -206,8 +222,7 @@ nvdb_status search_sub_batch(nvdb_hip_group* g, const float* queries, uint32_t n
   return NVDB_OK;
 }
 
-// the round-2 flow, kept for what the device exchange does not take (nshards * k beyond the merge kernel, a tripped
-// self-check): every shard through the host API (which retries and falls back by itself), lists merged on the host
+// the round-2 flow, kept for what the device exchange does not take (a tripped self-check): every shard through the host API (which retries and falls back by itself), lists merged on the host
 nvdb_status search_host_merge(nvdb_hip_group* g, const float* queries, uint32_t nq, uint32_t k, uint64_t* out_ids, float* out_scores) {
   const size_t G = g->ctx.size();
   const size_t per = static_cast<size_t>(nq) * k;
@@ -252,14 +267,17 @@ nvdb_status nvdb_hip_group_create(const int* devices, uint32_t n_devices, nvdb_h
   // RCCL wants distinct devices; NVDB_GROUP_NO_RCCL=1 forces the peer-copy exchange (tests)
   const bool distinct = std::set<int>(g->devices.begin(), g->devices.end()).size() == G;
   const char* off = std::getenv("NVDB_GROUP_NO_RCCL");
-  if (!distinct) g->why_not_rccl = "a device is listed more than once";
-  else if (off && off[0] == '1') g->why_not_rccl = "NVDB_GROUP_NO_RCCL=1";
-  else if (!rccl().ok()) g->why_not_rccl = rccl().why;
+  const char* lib = std::getenv("NVDB_GROUP_RCCL_LIB");
+  const bool no_rccl = off && off[0] == '1';
+  Rccl* R = (no_rccl || (!distinct && !(lib && lib[0]))) ? nullptr : &rccl(lib ? lib : "");
+  if (no_rccl) g->why_not_rccl = "NVDB_GROUP_NO_RCCL=1";
+  else if (!R) g->why_not_rccl = "a device is listed more than once";
+  else if (!R->ok()) g->why_not_rccl = R->why;
   else {
     g->comm.assign(G, nullptr);
-    const ncclResult_t r = rccl().CommInitAll(g->comm.data(), static_cast<int>(G), g->devices.data());
-    if (r != ncclSuccess) { g->why_not_rccl = std::string("ncclCommInitAll: ") + rccl().GetErrorString(r); g->comm.clear(); }
-    else g->use_rccl = true;
+    const ncclResult_t r = R->CommInitAll(g->comm.data(), static_cast<int>(G), g->devices.data());
+    if (r != ncclSuccess) { g->why_not_rccl = std::string("ncclCommInitAll: ") + R->GetErrorString(r); g->comm.clear(); }
+    else { g->use_rccl = true; g->R = R; }
   }
   *out = g;
   return NVDB_OK;
@@ -268,7 +286,7 @@ nvdb_status nvdb_hip_group_create(const int* devices, uint32_t n_devices, nvdb_h
 void nvdb_hip_group_destroy(nvdb_hip_group* g) {
   if (!g) return;
   for (size_t i = 0; i < g->stream.size(); ++i) { (void)hipSetDevice(g->devices[i]); (void)hipStreamSynchronize(g->stream[i]); }
-  for (ncclComm_t c : g->comm) if (c) (void)rccl().CommDestroy(c);
+  for (ncclComm_t c : g->comm) if (c && g->R) (void)g->R->CommDestroy(c);
   for (size_t i = 0; i < g->ctx.size(); ++i) {       // only devices a context was created on (a bad ordinal never reaches HIP)
     (void)hipSetDevice(g->devices[i]);
     for (auto* v : {&g->dq, &g->packed, &g->gathered}) if (i < v->size() && (*v)[i]) (void)hipFree((*v)[i]);
@@ -289,7 +307,7 @@ nvdb_hip_ctx* nvdb_hip_group_ctx(nvdb_hip_group* g, uint32_t shard) { return (g 
 
 int nvdb_hip_group_exchange(const nvdb_hip_group* g, const char** why) {
   if (!g) return -1;
-  if (why) *why = g->use_rccl ? "rccl all-gather" : g->why_not_rccl.c_str();
+  if (why) *why = g->use_rccl ? (g->R->override_lib ? "rccl all-gather (library named by NVDB_GROUP_RCCL_LIB)" : "rccl all-gather") : g->why_not_rccl.c_str();
   return g->use_rccl ? 1 : 0;
 }
 
@@ -344,20 +362,15 @@ nvdb_status nvdb_hip_group_search_batch(nvdb_hip_group* g, const float* queries,
   if (out_k_eff) *out_k_eff = static_cast<uint32_t>(std::min<uint64_t>(k, g->n));
   const uint64_t fb0 = g->fallbacks;
   if (nq && k) {
-    const size_t G = g->ctx.size();
-    // the merge kernel sorts nshards * k entries in LDS: larger k goes through the host merge
-    const bool dev_merge = static_cast<uint64_t>(G) * k <= 4096;
     for (uint32_t q0 = 0; q0 < nq; q0 += 1024) {
       const uint32_t b = std::min<uint32_t>(1024, nq - q0);
       const float* q = queries + static_cast<size_t>(q0) * g->dim;
       uint64_t* oi = out_ids + static_cast<size_t>(q0) * k;
       float* os = out_scores + static_cast<size_t>(q0) * k;
-      nvdb_status st = NVDB_ERR_INTERNAL;
-      if (dev_merge) {
-        if ((st = ensure_buffers(g, b, k))) return st;
-        st = search_sub_batch(g, q, b, k, oi, os);
-      }
-      if (st == NVDB_ERR_INTERNAL) st = search_host_merge(g, q, b, k, oi, os);
+      nvdb_status st;
+      if ((st = ensure_buffers(g, b, k))) return st;
+      st = search_sub_batch(g, q, b, k, oi, os);
+      if (st == NVDB_ERR_INTERNAL) st = search_host_merge(g, q, b, k, oi, os);     // a shard's self-check tripped
       if (st) return st;
       g->searches++;
     }

@@ -2045,14 +2045,23 @@ nvdb_status nvdb_hip_merge_topk_strided_dev(nvdb_hip_ctx* c, const uint64_t* dev
   if (!c) return NVDB_ERR_INVALID;
   if (!dev_ids || !dev_scores || !dev_out_ids || !dev_out_scores) return fail(c, NVDB_ERR_INVALID, "merge_topk: null pointer");
   if (nshards == 0 || nq == 0 || k == 0) return NVDB_OK;
-  const uint32_t m = nshards * k;
-  if (m > 4096) return fail(c, NVDB_ERR_UNSUPPORTED, "merge_topk: nshards*k must be <= 4096");
+  const uint64_t m64 = static_cast<uint64_t>(nshards) * k;
+  if (m64 >= (1ull << 31) || nq > 65535) return fail(c, NVDB_ERR_UNSUPPORTED, "merge_topk: nshards*k must be < 2^31 and nq <= 65535");
+  const uint32_t m = static_cast<uint32_t>(m64);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-  const size_t lds = ((m * 4 + 15) & ~15u) + static_cast<size_t>(m) * 8;
-  merge_topk_kernel<<<nq, 256, lds, s>>>(reinterpret_cast<const unsigned long long*>(dev_ids), dev_scores, nshards, nq, k,
-                                         reinterpret_cast<unsigned long long*>(dev_out_ids), dev_out_scores, stride_ids_bytes,
-                                         stride_scores_bytes);
+  if (m <= 4096) {
+    // every entry ranks itself against all others out of LDS (the lists need not be sorted)
+    const size_t lds = ((m * 4 + 15) & ~15u) + static_cast<size_t>(m) * 8;
+    merge_topk_kernel<<<nq, 256, lds, s>>>(reinterpret_cast<const unsigned long long*>(dev_ids), dev_scores, nshards, nq, k,
+                                           reinterpret_cast<unsigned long long*>(dev_out_ids), dev_out_scores, stride_ids_bytes,
+                                           stride_scores_bytes);
+  } else {
+    // longer lists: one binary search per other shard (the per-shard lists are sorted best-first, as every search path emits them)
+    merge_topk_sorted_kernel<<<dim3((m + 255) / 256, nq), 256, 0, s>>>(reinterpret_cast<const unsigned long long*>(dev_ids), dev_scores, nshards, nq, k,
+                                                                      reinterpret_cast<unsigned long long*>(dev_out_ids), dev_out_scores,
+                                                                      stride_ids_bytes, stride_scores_bytes);
+  }
   HIPCHK(c, hipGetLastError());
   return NVDB_OK;
 }
