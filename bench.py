@@ -317,8 +317,16 @@ def cli_legs(nvdb_amd, args, base_p, N, tmpdir):
 
 def _pinned_child(cmd, env, cpu, timeout=300):
     """run a single-threaded CPU child pinned to one CPU (both binaries of an A/B on the SAME core)"""
-    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, check=True,
-                          preexec_fn=(lambda: os.sched_setaffinity(0, {cpu})) if cpu is not None else None).stdout
+    # no preexec_fn: this process holds a HIP context (runtime threads alive), and Python code between fork and exec in a
+    # multi-threaded parent can deadlock.  The affinity is set on THIS thread and inherited by the child, then restored.
+    if cpu is None:
+        return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, check=True).stdout
+    aff = os.sched_getaffinity(0)
+    try:
+        os.sched_setaffinity(0, {cpu})
+        return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, check=True).stdout
+    finally:
+        os.sched_setaffinity(0, aff)
 
 
 def config0_plumbing(nvdb_amd, args):
@@ -506,6 +514,7 @@ def main():
 
     # ---- N > 1: the merged lists of one step against the unsharded corpus on rank 0 -------------------------
     merge_check = None
+    one_gpu_ms = None
     if use_dist and not args.no_verify_merge:
         step(0)
         torch.cuda.synchronize()
@@ -514,6 +523,19 @@ def main():
                 full = nvdb_amd.HipContext(local_rank)
                 full.generate_corpus(SEED, N, D, dt, row_base=0)       # 153.6 GB at N=100M: fits beside the rank's shard
                 fi, fs = full.search_batch(qhost[:B], K)
+                # the SAME corpus on ONE GPU, timed here so that this line carries its own 1-GPU point (3 passes after the warm one above,
+                # device-resident like the timed region): strong_scaling_efficiency = value / (N x this)
+                strm = torch.cuda.current_stream().cuda_stream
+                o_i = torch.empty((B, K), dtype=torch.int64, device=dev)
+                o_s = torch.empty((B, K), dtype=torch.float32, device=dev)
+                full.search_batch_dev(qdev[:B].data_ptr(), B, K, o_i.data_ptr(), o_s.data_ptr(), strm)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(3):
+                    full.search_batch_dev(qdev[(i % nbatches) * B:(i % nbatches + 1) * B].data_ptr(), B, K, o_i.data_ptr(), o_s.data_ptr(), strm)
+                torch.cuda.synchronize()
+                one_gpu_ms = (time.perf_counter() - t0) * 1e3 / 3
+                full.search_check()
                 full.close()
                 mi, ms_ = m_ids.cpu().numpy().astype(np.uint64), m_sc.cpu().numpy()
                 merge_check = bool(np.array_equal(mi, fi) and np.array_equal(ms_.view(np.uint32), fs.view(np.uint32)))
@@ -533,6 +555,34 @@ def main():
 
     qps = args.steps * B / elapsed
     ms_per_step = elapsed * 1e3 / args.steps
+
+    # ---- N > 1: where a step's time goes (events on the bench stream around search / all-gather / merge; a few extra, untimed
+    # steps after the timed region; per phase the MAX over ranks of the per-rank mean) ---------------------------------------
+    step_split = None
+    if use_dist and not share_gpu:
+        nsp = max(2, min(args.steps, 8))
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(nsp)]
+        barrier()
+        for i in range(nsp):
+            stream = torch.cuda.current_stream().cuda_stream
+            q = qdev[(i % nbatches) * B:(i % nbatches + 1) * B]
+            evs[i][0].record()
+            ctx.search_batch_dev(q.data_ptr(), B, K, out_ids.data_ptr(), out_sc.data_ptr(), stream)
+            evs[i][1].record()
+            dist.all_gather_into_tensor(gathered, packed)
+            evs[i][2].record()
+            ctx.merge_topk_strided_dev(gathered.data_ptr(), gathered.data_ptr() + B * K * 8, PACK, PACK, world, B, K, m_ids.data_ptr(), m_sc.data_ptr(), stream)
+            evs[i][3].record()
+        barrier()
+        ctx.search_check()
+        mine = [sum(e[j].elapsed_time(e[j + 1]) for e in evs) / nsp for j in range(3)]
+        tt = torch.tensor(mine, dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sp = [float(x) for x in tt.tolist()]
+        step_split = {"search_ms": sp[0], "allgather_ms": sp[1], "merge_ms": sp[2], "steps": nsp,
+                      "note": "HIP events on the bench stream around the three phases of a step, extra untimed steps; per phase the MAX over "
+                              "ranks of the per-rank mean.  allgather_ms includes waiting for the slowest rank's search (the collective "
+                              "starts when every rank has reached it)"}
     out = {
         "metric": "QPS + effective HBM GB/s, flat-scan top-10 d=768",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -542,11 +592,17 @@ def main():
                                + (" (BASELINE configs[1])" if (N, world) == (ROWS_1GPU, 1) else " (BASELINE configs[3])" if N == ROWS_SHARDED else ""),
                    "rows_total": N, "rows_per_gpu": hi - lo, "batch": B, "k": K, "dim": D,
                    "parallelism": "1 GPU" if world == 1 else f"corpus row-sharded x{world}, RCCL all-gather of per-shard top-k",
-                   "series": "strong scaling over the 100M-row corpus; its 1-GPU point is extras.fp16_100M_batch1024 (= scaling_points.fp16_100M_batch1024_qps) of the --gpus 1 line" if (world > 1 and N == ROWS_SHARDED) else None},
+                   "series": "strong scaling over the 100M-row corpus; its 1-GPU point is measured in THIS run (one_gpu_same_corpus: the unsharded corpus on rank 0's GPU) and also reported as extras.fp16_100M_batch1024 of the --gpus 1 line.  Do NOT divide this value by the --gpus 1 line's value: that one is the 10M-row corpus of configs[1]" if (world > 1 and N == ROWS_SHARDED) else None},
         "effective_hbm_GBps": (N * bpr / 1e9) / (ms_per_step * 1e-3),          # corpus bytes / pass time, all GPUs
         "parity": parity, "merge_check": merge_check,
         "exchange": (("gloo on host copies (NVDB_BENCH_SHARE_GPU rehearsal)" if share_gpu else f"RCCL all-gather of {PACK} packed bytes per rank, backend {dist.get_backend()}, world {world}")
                      + (" -- forced at world 1 (NVDB_BENCH_FORCE_COLLECTIVE)" if world == 1 else "")) if use_dist else None,
+        "step_split_ms": step_split,
+        "one_gpu_same_corpus": ({"qps": B / (one_gpu_ms * 1e-3), "ms_per_step": one_gpu_ms,
+                                 "what": f"the UNSHARDED {N}-row corpus resident on rank 0's GPU alone (the context merge_check builds), same batch, "
+                                         "device-resident queries and results, 3 timed passes -- this line's own 1-GPU point",
+                                 "strong_scaling_efficiency": qps / (world * B / (one_gpu_ms * 1e-3)),
+                                 "efficiency_is": "value / (n_gpus x one_gpu_same_corpus.qps)"} if one_gpu_ms else None),
         "self_check": "every timed step checked (sticky flags): no list overflow, no bound violation",
         "scan": {"path": stats["path"], "chunks": stats["chunks"], "candidates_per_query": stats["candidates"] / max(B, 1),
                  "bound_violations": stats["bound_violations"], "overflow_queries": stats["overflow_queries"]},
@@ -672,17 +728,31 @@ def main():
                                                            "wave_tiles": (N // 64) * ((bb + 63) // 64 if bb > 128 else (bb + 31) // 32)}}
             extras["sweep"]["int8"] = sweep_points(c8, D + 4, PEAK_I8_TOPS)
             c8.close()
-            # recall@10 of the int8 corpus against the fp32 corpus' exact top-10 (500K-row prefix, 64 queries)
-            nr = min(N, 500_000)
+            # recall@10 and score deltas of the int8 corpus against the fp32 corpus at configs[2]'s OWN size: all N rows, all B queries.
+            # Same synthetic rows (seed, row id), quantised per row as the reference's tool does (apps/nvdb_quantize_i8.cpp:71-80:
+            # scale = max|x| / 127, lrint(x / scale), clamp to [-127, 127]).  The fp32 corpus (30.7 GB + its fp16 filter shadow) is
+            # searched on the filter path: exact fp32-order scores of the fp32 rows.
             c32 = nvdb_amd.HipContext(local_rank)
-            c32.generate_corpus(SEED, nr, D, nvdb_amd.DT_F32)
-            g_ids, _ = c32.search_batch(qhost[:64], K)
+            c32.generate_corpus(SEED, N, D, nvdb_amd.DT_F32)
+            g_ids, g_sc = c32.search_batch(qhost[:B], K)
             c32.close()
             c8s = nvdb_amd.HipContext(local_rank)
-            c8s.generate_corpus(SEED, nr, D, nvdb_amd.DT_I8)
-            i_ids, _ = c8s.search_batch(qhost[:64], K)
+            c8s.generate_corpus(SEED, N, D, nvdb_amd.DT_I8)
+            i_ids, i_sc = c8s.search_batch(qhost[:B], K)
             c8s.close()
             extras["int8_recall_at_10_vs_fp32"] = float(np.mean([len(set(a.tolist()) & set(b_.tolist())) / K for a, b_ in zip(g_ids, i_ids)]))
+            same = i_ids[:, :, None] == g_ids[:, None, :]                               # [q][j int8][j' fp32]: the same row in both lists
+            d_same = np.abs(i_sc[:, :, None].astype(np.float64) - g_sc[:, None, :].astype(np.float64))[same]
+            d_rank = np.abs(i_sc.astype(np.float64) - g_sc.astype(np.float64))
+            extras["int8_vs_fp32"] = {"workload": f"int8+scale vs fp32 flat-scan top-{K}, N={N} d={D}, {B} queries (BASELINE configs[2]: 'recall vs fp32 reported')",
+                                      "recall_at_k": extras["int8_recall_at_10_vs_fp32"], "k": K, "queries": B, "rows": N,
+                                      "queries_with_identical_id_sets": int(sum(set(a.tolist()) == set(b_.tolist()) for a, b_ in zip(g_ids, i_ids))),
+                                      "top1_agrees": float(np.mean(i_ids[:, 0] == g_ids[:, 0])),
+                                      "score_delta_same_row": {"max": float(d_same.max()), "mean": float(d_same.mean()), "pairs": int(d_same.size),
+                                                               "what": "|score_int8 - score_fp32| of every row that is in both returned lists"},
+                                      "score_delta_rankwise": {"max": float(d_rank.max()), "mean": float(d_rank.mean()),
+                                                               "what": "|j-th best int8 score - j-th best fp32 score| over all queries and ranks"},
+                                      "quantiser": "per-row scale = max|x|/127, lrint, clamp [-127,127] (reference apps/nvdb_quantize_i8.cpp:71-80)"}
             # (3) BASELINE configs[4]: exact-L2 refine, N=2.9M fp16, Q=10000, R=1024, K=10, synthetic candidates
             NR, QR, RR = min(N, 2_900_000), 10_000, 1024
             cr = nvdb_amd.HipContext(local_rank)

@@ -292,6 +292,17 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(
   }
 }
 
+// Everything this search's self-checks found goes into the STICKY words any_overflow[6..8] (= misc[12..14]), which survive later
+// searches until nvdb_hip_search_check reads and clears them.  any_overflow[-6], [-5] = misc[0], misc[1]: bound violations and
+// wave-log overflow -- final only when every kernel (and, in the fused rescore + select kernel, every workgroup) that can raise
+// them has finished: one thread of the search's last workgroup calls this.
+__device__ __forceinline__ void fold_sticky_words(uint32_t* any_overflow) {
+  const uint32_t viol = __hip_atomic_load(any_overflow - 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t logovf = __hip_atomic_load(any_overflow - 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (viol) atomicAdd(any_overflow + 7, viol);
+  if (logovf) atomicOr(any_overflow + 8, 1u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // select: sort a query's candidate list (score desc, id asc) in LDS, then either
 //   mode 0: thr[q] = (k-th score) - slack[q]; keep every entry with score >= thr (all of the top-k
@@ -300,15 +311,17 @@ __global__ __launch_bounds__(256) void scan_exact_kernel(
 //   mode 2: like mode 0 but the list is emptied afterwards (thresholds from bootstrap tile maxima).
 // grid = nq, block = 64..256 (any multiple of 64), dynamic LDS = cap * 8 bytes.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void select_kernel(
+// The body works on ONE query with all `nth` threads of the calling workgroup and `e` = LDS for the list (cap rounded up to a
+// power of two entries): select_kernel calls it for blockIdx.x; the kernels that fold a select into their own tail
+// (rescore_lds_kernel: the final select; the filter kernels of a few-query search: the per-chunk thresholds, kernels_filter.h
+// fused_select_tail) call it too -- one implementation, one order.  Every thread of the workgroup must make the call.
+__device__ __forceinline__ void select_body(
+    const uint32_t q, const uint32_t tid, const uint32_t nth, Cand* e,
     Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t k, const float* __restrict__ slack,
     float* __restrict__ thr, uint32_t* __restrict__ overflow, int mode, uint64_t row_base,
     unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, uint32_t out_k, uint32_t* __restrict__ any_overflow,
-    float* __restrict__ xcdw) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  Cand* e = reinterpret_cast<Cand*>(smem_raw);
+    float* __restrict__ xcdw, bool fold_sticky) {
   __shared__ uint32_t s_keep;
-  const uint32_t q = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
   // XCD balance (kernels_filter.h, ScatterArgs::xcdw): the filter launch before this kernel filed tile-loop time and tile
   // counts per XCD label; turn them into the relative speeds the next launch partitions its tiles by.  Half-way steps,
   // a +-10 % cage and renormalisation to mean 1 keep one odd launch from skewing the shares.
@@ -346,11 +359,7 @@ __global__ __launch_bounds__(256) void select_kernel(
   // neither set nor clear what device-API searches left for the next nvdb_hip_search_check.
   if ((mode & 1) && tid == 0) {
     if (overflow[q]) { atomicOr(any_overflow, 1u); if (mode == 1) atomicOr(any_overflow + 6, 1u); }
-    if (mode == 1 && q == 0) {
-      const uint32_t viol = any_overflow[-6], logovf = any_overflow[-5];
-      if (viol) atomicAdd(any_overflow + 7, viol);
-      if (logovf) atomicOr(any_overflow + 8, 1u);
-    }
+    if (mode == 1 && fold_sticky) fold_sticky_words(any_overflow);
   }
   Cand* mine = cand + static_cast<uint64_t>(q) * cap;
   if (m <= 512) {
@@ -445,6 +454,17 @@ __global__ __launch_bounds__(256) void select_kernel(
   const uint32_t keep = s_keep;                          // sorted list -> the kept ones are a prefix
   for (uint32_t i = tid; i < keep; i += nth) mine[i] = e[i];
   if (tid == 0) { cnt[q] = (mode == 2) ? 0u : keep; thr[q] = t; }
+}
+
+__global__ __launch_bounds__(256) void select_kernel(
+    Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t k, const float* __restrict__ slack,
+    float* __restrict__ thr, uint32_t* __restrict__ overflow, int mode, uint64_t row_base,
+    unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, uint32_t out_k, uint32_t* __restrict__ any_overflow,
+    float* __restrict__ xcdw) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // (every earlier kernel of the search has completed when this one runs: block 0 may fold the self-check words)
+  select_body(blockIdx.x, threadIdx.x, blockDim.x, reinterpret_cast<Cand*>(smem_raw), cand, cnt, cap, k, slack, thr, overflow, mode, row_base,
+              out_ids, out_scores, out_k, any_overflow, xcdw, blockIdx.x == 0);
 }
 
 // one launch that resets all per-search words: list lengths, overflow flags, thresholds (-inf), self-check words

@@ -4,7 +4,7 @@
 // status becomes std::runtime_error (reference convention, src/flat_index.cpp:17).
 #pragma once
 #include <cstdint>
-#include <mutex>
+#include <memory>
 #include <vector>
 
 #include "nvdb/topK.h"
@@ -15,6 +15,8 @@ struct nvdb_hip_group;
 
 namespace nvdb {
 
+namespace detail { class CallCoalescer; }        // flat_index_hip.cpp: concurrent callers of one index share GPU batches
+
 class FlatIndexHIP {
  public:
   // Uploads the dataset's rows to HBM once (device `device`); ids returned are row_base + row.
@@ -23,8 +25,12 @@ class FlatIndexHIP {
   FlatIndexHIP(const FlatIndexHIP&) = delete;
   FlatIndexHIP& operator=(const FlatIndexHIP&) = delete;
 
-  // Like FlatIndex / FlatIndexOMP::search_topk_dot (const, callable from several threads at once): the device context
-  // behind it is single-owner, so concurrent callers take turns (one search at a time per index; batch to use the GPU).
+  // Like FlatIndex / FlatIndexOMP::search_topk_dot (const, callable from several threads at once: reference
+  // include/nvdb/flat_index.h:11-16).  The device context behind it is single-owner and a batch of 8 costs the GPU what one
+  // query costs, so callers that overlap are COALESCED: whoever finds the context free becomes the leader, gathers the
+  // queries that queued meanwhile (same k, up to 1024 in all; after a shared batch it lingers <= 50 us for the same callers
+  // to come back), runs ONE nvdb_hip_search_batch and hands every caller its rows.  A lone caller never waits.  Results are
+  // per query and do not depend on the batch they rode in.
   std::vector<SearchResult> search_topk_dot(const float* q, uint32_t k) const;
   // nq queries [nq][dim]; result [nq][min(k,N)] row-major, best first
   std::vector<SearchResult> search_topk_dot_batch(const float* queries, uint32_t nq, uint32_t k) const;
@@ -36,7 +42,7 @@ class FlatIndexHIP {
   uint64_t n_ = 0;
   uint32_t dim_ = 0;
   mutable double last_kernel_ms_ = 0.0;
-  mutable std::mutex mu_;                          // one search at a time on the context
+  std::unique_ptr<detail::CallCoalescer> calls_;   // one GPU batch at a time on the context, shared by the callers that overlap
 };
 
 // Row-sharded flat index over several GPUs of one node, driven from ONE process (the reference has no multi-GPU path):
@@ -64,7 +70,7 @@ class FlatIndexHIPSharded {
   uint64_t n_ = 0;
   uint32_t dim_ = 0;
   mutable unsigned fallbacks_ = 0;
-  mutable std::mutex mu_;                          // one search at a time on the group
+  std::unique_ptr<detail::CallCoalescer> calls_;   // one batch at a time on the group, shared by the callers that overlap
 };
 
 }  // namespace nvdb

@@ -4,6 +4,7 @@
 // tests can call the nvdb:: host functions directly through ctypes and compare them with the reference goldens --
 // the dot kernels on both dispatch branches, f16_to_f32_scalar / base_row_to_f32 (reference f16_scalar.h,
 // to_f32_row.h) and the CPU refine (apps/nvdb_ivf_eval.cpp:232-240, 278-307).
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <exception>
@@ -90,6 +91,42 @@ int nvdb_host_hip_concurrent_search(void* h, const float* queries, uint32_t nq, 
         } catch (const std::exception& e) { errs[static_cast<size_t>(t)] = e.what(); }
       });
     for (auto& x : th) x.join();
+    for (const auto& e : errs) if (!e.empty()) { g_err = e; return -1; }
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+// Throughput of overlapping single-query callers (the coalescing of FlatIndexHIP::search_topk_dot): out_ms[0] = one thread running
+// `reps` single-query searches, out_ms[1] = `threads` threads running `reps` each at the same time (thread t cycles through the
+// queries t, t + threads, ...).  Every result is compared with out-of-band batched answers by the caller through out_ids / out_scores
+// of the LAST search of each query index.
+int nvdb_host_hip_concurrent_timing(void* h, const float* queries, uint32_t nq, uint32_t k, int threads, uint32_t reps, uint64_t* out_ids,
+                                    float* out_scores, double* out_ms) {
+  try {
+    const auto* ds = static_cast<nvdb::VectorDataset*>(h);
+    nvdb::FlatIndexHIP idx(ds);
+    const uint32_t dim = ds->dim();
+    auto one = [&](uint32_t q) {
+      const std::vector<nvdb::SearchResult> r = idx.search_topk_dot(queries + static_cast<size_t>(q) * dim, k);
+      for (uint32_t j = 0; j < k; ++j) {
+        out_ids[static_cast<size_t>(q) * k + j] = j < r.size() ? r[j].id : ~0ull;
+        out_scores[static_cast<size_t>(q) * k + j] = j < r.size() ? r[j].score : -__builtin_huge_valf();
+      }
+    };
+    for (uint32_t i = 0; i < 5; ++i) one(i % nq);                                        // warm-up: buffers, kernels
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < reps; ++i) one(i % nq);
+    out_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<std::string> errs(static_cast<size_t>(threads));
+    std::vector<std::thread> th;
+    t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; ++t)
+      th.emplace_back([&, t] {
+        try { for (uint32_t i = 0; i < reps; ++i) one((static_cast<uint32_t>(t) + i * static_cast<uint32_t>(threads)) % nq); }
+        catch (const std::exception& e) { errs[static_cast<size_t>(t)] = e.what(); }
+      });
+    for (auto& x : th) x.join();
+    out_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (const auto& e : errs) if (!e.empty()) { g_err = e; return -1; }
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }

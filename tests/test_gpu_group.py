@@ -7,6 +7,7 @@ on devices[0]) and the RCCL branch of bench.py, on the ONE GPU a test box has:
                             same merge kernel: three shards with global ids == the unsharded search, bit for bit.
   * bench.py with NVDB_BENCH_FORCE_COLLECTIVE=1 and one rank: init_process_group("nccl"), the packed uint8 all-gather,
     nvdb_hip_merge_topk_strided_dev, merge_check -- the code path the 8-GPU run takes.
+  * devices = [0] * G with NVDB_GROUP_RCCL_LIB naming tests/loopback_rccl's stand-in -> the RCCL branch with G = 2, 3, 8 ranks.
 The 8-GPU exchange itself cannot run here; what these tests show is that every call of that path initialises, orders
 its streams and merges correctly."""
 import json
@@ -55,6 +56,50 @@ def test_group_search_equals_the_unsharded_search(devices, mode, dtype):
     g.close()
 
 
+LOOPBACK = os.path.join(ROOT, "tests", "loopback_rccl", "libloopback_rccl.so")
+
+
+def _loopback_counters():
+    import ctypes as C
+    L = C.CDLL(LOOPBACK, mode=C.RTLD_GLOBAL)
+    out = (C.c_int * 4)()
+    L.nvdb_loopback_rccl_counters(out)
+    return list(out)
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_group_rccl_branch_with_several_ranks_through_the_loopback_stand_in(G, monkeypatch):
+    """The group's RCCL branch -- ncclCommInitAll, ncclGroupStart / G x ncclAllGather / ncclGroupEnd on the G streams, the merge out
+    of devices[0]'s gathered buffer -- with G ranks on ONE device.  RCCL itself refuses a repeated device; NVDB_GROUP_RCCL_LIB
+    names a stand-in (tests/loopback_rccl, test infrastructure) that implements the all-gather's ordering semantics with stream
+    events and copies into recv + rank * count.  What this executes of the 8-GPU path: receive offsets, which buffers are handed
+    to which rank's call, stream order between search, exchange, merge and the next batch, communicator reuse."""
+    if not os.path.exists(LOOPBACK):
+        subprocess.run(["make", "-C", os.path.dirname(LOOPBACK)], check=True)
+    monkeypatch.setenv("NVDB_GROUP_RCCL_LIB", LOOPBACK)
+    n, d, k = 600_000, 768, 10
+    batches = [nvdb_amd.synth_rows_f32(SEED + 70 + i, 0, nq, d) for i, nq in enumerate((300, 64, 1024, 5))]
+    want = [_reference_search(n, d, nvdb_amd.DT_F16, q, k) for q in batches]
+    c0 = _loopback_counters()
+    g = nvdb_amd.DeviceGroup([0] * G)
+    mode, why = g.exchange()
+    assert mode == "rccl" and "NVDB_GROUP_RCCL_LIB" in why, (mode, why)
+    g.generate_corpus(SEED + 30, n, d, nvdb_amd.DT_F16)
+    calls = 0
+    for rep in range(2):                                        # second round: same communicators, same buffers
+        for q, (fi, fs) in zip(batches, want):                  # different batch sizes back to back: a stale block would show
+            ids, sc, st = g.search_batch(q, k, want_stats=True)
+            calls += 1
+            assert st["shards"] == G and st["exchange"] == 1 and st["host_merge_fallbacks"] == 0
+            assert st["bytes_per_rank"] == len(q) * k * 12
+            assert np.array_equal(ids, fi) and np.array_equal(sc.view(np.uint32), fs.view(np.uint32)), (G, rep, len(q))
+    c1 = _loopback_counters()
+    assert c1[0] - c0[0] == 1, "communicators must be created once per group"
+    assert c1[1] - c0[1] == G * calls and c1[2] - c0[2] == calls
+    g.close()
+    assert _loopback_counters()[3] - c0[3] == G
+
+
 def test_group_uploads_a_host_corpus_in_row_shards(oracle):
     n, d, nq, k = 90_000, 768, 40, 10
     base = oracle.f32_to_f16(nvdb_amd.synth_rows_f32(SEED + 32, 0, n, d))
@@ -79,11 +124,19 @@ def test_group_more_than_1024_queries_and_large_k():
     ids, sc, st = g.search_batch(queries, 10, want_stats=True)
     assert st["host_merge_fallbacks"] == 0
     assert np.array_equal(ids, fi) and np.array_equal(sc.view(np.uint32), fs.view(np.uint32))
-    # 2 shards x k = 3000 > 4096 entries per query: beyond the merge kernel's LDS -> host merge, same answer
+    # 2 shards x k = 3000 > 4096 entries per query: beyond the LDS-ranked merge -> the sorted-list merge on the device, same answer
     fi, fs = _reference_search(n, d, nvdb_amd.DT_F16, queries[:20], 3000)
     ids, sc, st = g.search_batch(queries[:20], 3000, want_stats=True)
-    assert st["host_merge_fallbacks"] == 1
+    assert st["host_merge_fallbacks"] == 0
     assert np.array_equal(ids, fi) and np.array_equal(sc.view(np.uint32), fs.view(np.uint32))
+    # k = 1000 at 8 shards (8000 entries per query; the reference bounds k by N only, src/flat_index.cpp:24)
+    g8 = nvdb_amd.DeviceGroup([0] * 8)
+    g8.generate_corpus(SEED + 30, n, d, nvdb_amd.DT_F16)
+    fi, fs = _reference_search(n, d, nvdb_amd.DT_F16, queries[:12], 1000)
+    ids, sc, st = g8.search_batch(queries[:12], 1000, want_stats=True)
+    assert st["host_merge_fallbacks"] == 0 and st["shards"] == 8
+    assert np.array_equal(ids, fi) and np.array_equal(sc.view(np.uint32), fs.view(np.uint32))
+    g8.close()
     # k beyond a shard's row count: clamped to the corpus size, padded shard lists merge correctly
     g2 = nvdb_amd.DeviceGroup([0, 0, 0])
     g2.generate_corpus(SEED + 30, 3000, d, nvdb_amd.DT_F16)
@@ -159,6 +212,12 @@ def test_bench_rccl_branch_with_one_rank():
     assert "backend nccl" in line["exchange"] and "world 1" in line["exchange"]
     assert line["parity"].startswith("ok") and line["scan"]["path"] == 2 and line["scan"]["bound_violations"] == 0
     assert line["n_gpus"] == 1 and line["value"] > 0
+    # every N > 1 line is self-contained: its own 1-GPU point of the same corpus and the search / all-gather / merge split
+    one = line["one_gpu_same_corpus"]
+    assert one["qps"] > 0 and 0.7 < one["strong_scaling_efficiency"] < 1.3, one          # world 1: the "sharded" run IS the one-GPU run
+    sp = line["step_split_ms"]
+    assert sp["search_ms"] > 0 and sp["allgather_ms"] >= 0 and sp["merge_ms"] > 0
+    assert sp["search_ms"] + sp["allgather_ms"] + sp["merge_ms"] < 1.3 * line["ms_per_step"], (sp, line["ms_per_step"])
 
 
 @pytest.mark.parametrize("devices", [None, [0, 0]])
@@ -190,3 +249,42 @@ def test_index_objects_take_concurrent_callers(tmp_path, oracle, devices):
     L.nvdb_host_dataset_close(h)
     assert rc == 0, L.nvdb_host_last_error()
     assert np.array_equal(ids, want_i) and np.array_equal(sc.view(np.uint32), want_s.view(np.uint32))
+
+
+def test_overlapping_single_query_callers_share_gpu_batches(tmp_path, oracle):
+    """nvdb::FlatIndexHIP::search_topk_dot coalesces callers that overlap (host/src/flat_index_hip.cpp, CallCoalescer): six threads
+    x 50 single queries must finish in less than twice the time of one thread's 50 (serialised under a mutex it was ~6x), and
+    every query's rows equal the batched answer bit for bit.  Reference: FlatIndex::search_topk_dot is const and re-entrant
+    (include/nvdb/flat_index.h:11-16)."""
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "nano-vectordb_amd", "lib", "libnvdb_host_capi.so"))
+    L.nvdb_host_dataset_open.restype = C.c_void_p
+    L.nvdb_host_dataset_open.argtypes = [C.c_char_p]
+    L.nvdb_host_dataset_close.argtypes = [C.c_void_p]
+    L.nvdb_host_last_error.restype = C.c_char_p
+    L.nvdb_host_hip_concurrent_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    n, d, nq, k, threads, reps = 500_000, 384, 96, 10, 6, 50      # the reference's own corpus size and dimension (Performance.md:43)
+    base = oracle.f32_to_f16(nvdb_amd.synth_rows_f32(SEED + 62, 0, n, d))
+    queries = np.ascontiguousarray(nvdb_amd.synth_rows_f32(SEED + 63, 0, nq, d))
+    p = str(tmp_path / "b16.vecbin")
+    po.write_vecbin(p, base, po.DT_F16)
+    c = nvdb_amd.HipContext(0)
+    c.upload_corpus(base, nvdb_amd.DT_F16)
+    want_i, want_s = c.search_batch(queries, k)
+    c.close()
+    h = L.nvdb_host_dataset_open(p.encode())
+    assert h, L.nvdb_host_last_error()
+    ids = np.zeros((nq, k), np.uint64); sc = np.zeros((nq, k), np.float32)
+    ms = (C.c_double * 2)()
+    best = None
+    for attempt in range(3):                                    # wall-clock ratio on a shared host: best of three
+        rc = L.nvdb_host_hip_concurrent_timing(h, queries.ctypes.data, nq, k, threads, reps, ids.ctypes.data, sc.ctypes.data, ms)
+        assert rc == 0, L.nvdb_host_last_error()
+        assert np.array_equal(ids, want_i) and np.array_equal(sc.view(np.uint32), want_s.view(np.uint32))
+        ratio = ms[1] / ms[0]
+        best = ratio if best is None else min(best, ratio)
+        print(f"one thread x {reps}: {ms[0]:.2f} ms; {threads} threads x {reps}: {ms[1]:.2f} ms; ratio {ratio:.2f}")
+        if best < 2.0:
+            break
+    L.nvdb_host_dataset_close(h)
+    assert best < 2.0, best
