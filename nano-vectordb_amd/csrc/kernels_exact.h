@@ -312,9 +312,8 @@ __device__ __forceinline__ void fold_sticky_words(uint32_t* any_overflow) {
 // grid = nq, block = 64..256 (any multiple of 64), dynamic LDS = cap * 8 bytes.
 // ------------------------------------------------------------------------------------------------
 // The body works on ONE query with all `nth` threads of the calling workgroup and `e` = LDS for the list (cap rounded up to a
-// power of two entries): select_kernel calls it for blockIdx.x; the kernels that fold a select into their own tail
-// (rescore_lds_kernel: the final select; the filter kernels of a few-query search: the per-chunk thresholds, kernels_filter.h
-// fused_select_tail) call it too -- one implementation, one order.  Every thread of the workgroup must make the call.
+// power of two entries): select_kernel calls it for blockIdx.x, and rescore_lds_kernel, which folds the final select into its
+// own tail, calls it too -- one implementation, one order.  Every thread of the workgroup must make the call.
 __device__ __forceinline__ void select_body(
     const uint32_t q, const uint32_t tid, const uint32_t nth, Cand* e,
     Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t k, const float* __restrict__ slack,
@@ -456,7 +455,7 @@ __device__ __forceinline__ void select_body(
   if (tid == 0) { cnt[q] = (mode == 2) ? 0u : keep; thr[q] = t; }
 }
 
-__global__ __launch_bounds__(256) void select_kernel(
+static __global__ __launch_bounds__(256) void select_kernel(
     Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t k, const float* __restrict__ slack,
     float* __restrict__ thr, uint32_t* __restrict__ overflow, int mode, uint64_t row_base,
     unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, uint32_t out_k, uint32_t* __restrict__ any_overflow,
@@ -468,7 +467,7 @@ __global__ __launch_bounds__(256) void select_kernel(
 }
 
 // one launch that resets all per-search words: list lengths, overflow flags, thresholds (-inf), self-check words
-__global__ __launch_bounds__(256) void init_search_kernel(uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow,
+static __global__ __launch_bounds__(256) void init_search_kernel(uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow,
                                                           float* __restrict__ thr, uint32_t* __restrict__ misc, uint32_t nq_pad,
                                                           uint32_t* __restrict__ prog, uint32_t prog_words) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -565,16 +564,34 @@ __global__ __launch_bounds__(256) void rescore8_kernel(
 // candidate rows of a pass with coalesced 16-byte loads (all in flight at once), then every group walks its row in
 // LDS.  Rows must be 16-byte multiples (the launcher falls back to rescore8_kernel otherwise); row slots are
 // padded by 16 bytes so that the eight groups of a wave start in different banks.
+// The final select folded into the rescore launch (same grid: one workgroup per query): after its candidates are re-scored the
+// workgroup orders ITS list and emits the top-k -- one launch fewer per search.  mode 0: no select here (the caller launches
+// select_kernel).  The self-check words are final only when EVERY workgroup has re-scored: the last one to take a ticket folds
+// them into the sticky words (mode 1) and, for the host API's small calls, copies the 8 status words to `status_out` (pinned
+// host memory the kernel writes directly, like out_ids / out_scores: no D2H copy is enqueued for them).
+struct FinalSelect {
+  int mode;                          // 0 none, 1 final select + sticky fold, 3 final select (host API: own words only)
+  uint32_t k, out_k;
+  uint64_t row_base;
+  unsigned long long* out_ids;
+  float* out_scores;
+  float* thr;
+  uint32_t* overflow;
+  uint32_t* any_overflow;            // = misc + 6
+  uint32_t* ticket;                  // zeroed by the search's init; null: no fold / no status copy
+  uint32_t* status_out;              // null: none
+};
+
 template <int DT>
 __global__ __launch_bounds__(256) void rescore_lds_kernel(
     const void* __restrict__ rows, const float* __restrict__ scales, uint32_t dim, const float* __restrict__ q32,
-    Cand* __restrict__ cand, const uint32_t* __restrict__ cnt, uint32_t cap, const float* __restrict__ ebound,
-    uint32_t* __restrict__ violations, unsigned long long* __restrict__ total_cands, uint32_t cpp) {
+    Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, const float* __restrict__ ebound,
+    uint32_t* __restrict__ violations, unsigned long long* __restrict__ total_cands, uint32_t cpp, FinalSelect fs) {
   constexpr uint32_t BPE = (DT == DT_F32) ? 4 : (DT == DT_F16 ? 2 : 1);
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
   uint32_t m = cnt[q];
   if (m > cap) m = cap;
-  if (m == 0) return;
+  if (m == 0 && fs.mode == 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const uint32_t qstride = (dim + 3u) & ~3u, row_bytes = dim * BPE, slot_bytes = row_bytes + 16, cpr = row_bytes >> 4;
   float* qptr = reinterpret_cast<float*>(smem_raw);
@@ -623,6 +640,25 @@ __global__ __launch_bounds__(256) void rescore_lds_kernel(
       }
     }
   }
+  if (fs.mode == 0) return;
+  __syncthreads();                                                 // my list's new scores are written (workgroup scope); the LDS is free
+  select_body(q, tid, 256u, reinterpret_cast<Cand*>(smem_raw), cand, cnt, cap, fs.k, nullptr, fs.thr, fs.overflow, fs.mode, fs.row_base,
+              fs.out_ids, fs.out_scores, fs.out_k, fs.any_overflow, nullptr, false);
+  if (fs.ticket == nullptr) return;
+  // what the last workgroup reads of the others are agent-scope atomics (violations, flags): performed once vmcnt is 0 -- no
+  // release fence (an L2 write-back per workgroup costs more than the select launch this fusion saves)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(fs.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {                                      // every workgroup of the search has finished
+      if (fs.mode == 1) fold_sticky_words(fs.any_overflow);
+      if (fs.status_out != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fs.status_out[i] = __hip_atomic_load(fs.any_overflow - 6 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -631,7 +667,7 @@ __global__ __launch_bounds__(256) void rescore_lds_kernel(
 // ------------------------------------------------------------------------------------------------
 // Shard s's ids start at ids + s*stride_ids_bytes, its scores at scores + s*stride_scores_bytes (so that one
 // all-gather of a packed [ids | scores] buffer per rank can be merged in place).
-__global__ __launch_bounds__(256) void merge_topk_kernel(
+static __global__ __launch_bounds__(256) void merge_topk_kernel(
     const unsigned long long* __restrict__ ids, const float* __restrict__ scores, uint32_t nshards, uint32_t nq,
     uint32_t k, unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, size_t stride_ids_bytes,
     size_t stride_scores_bytes) {
@@ -665,7 +701,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(
 // position plus, for every other shard, the number of that shard's entries that come before it -- one binary search per shard
 // straight out of the gathered buffer (L2).  Any k the flat path accepts (the reference bounds k by N only, flat_index.cpp:24).
 // Total order = merge_topk_kernel's: (score desc, id asc, flat position asc); ids are global, hence distinct except for padding.
-__global__ __launch_bounds__(256) void merge_topk_sorted_kernel(
+static __global__ __launch_bounds__(256) void merge_topk_sorted_kernel(
     const unsigned long long* __restrict__ ids, const float* __restrict__ scores, uint32_t nshards, uint32_t nq,
     uint32_t k, unsigned long long* __restrict__ out_ids, float* __restrict__ out_scores, size_t stride_ids_bytes,
     size_t stride_scores_bytes) {

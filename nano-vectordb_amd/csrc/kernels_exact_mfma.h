@@ -32,6 +32,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels_exact.h"
 #include "kernels_filter.h"        // glds16_v, NVDB_LPTR: direct-to-LDS loads issued from inline asm
 
@@ -560,6 +562,254 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_lds_kernel(
       }
     }
   }
+  if constexpr (!SCORES) {
+    for (uint32_t g = 0; g < EXACT_MFMA_QB; ++g) {
+      const uint32_t q = qg0 + wave * EXACT_MFMA_QB + g;
+      const uint32_t c = readlane_u(my_cnt, static_cast<int>(g));
+      if (c == 0) continue;
+      uint32_t slot0 = 0;
+      if (lane == 0) slot0 = atomicAdd(&cnt[q], c);
+      slot0 = readlane_u(slot0, 0);
+      if (static_cast<uint32_t>(lane) < c) {
+        const uint32_t slot = slot0 + lane;
+        if (slot < cap) cand[static_cast<uint64_t>(q) * cap + slot] = Cand{l_s[SCORES ? 0 : wave][SCORES ? 0 : g][lane], l_id[SCORES ? 0 : wave][SCORES ? 0 : g][lane]};
+        else overflow[q] = 1u;
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// fp16 / int8 rows through an fp32 LDS IMAGE (round 4).
+//
+// Every vector instruction between two fp32 MFMAs costs ~10 cycles of the matrix pipe (profiles/r03_mfma_f32_rate.txt), and the
+// kernels above convert an A operand right in front of each MFMA: 86 / 81 TFLOP/s for fp16 / int8 rows where fp32 rows, which
+// need no conversion, reach 101.  Here a tile is converted ONCE per workgroup: each of the four waves fetches a quarter of the
+// raw 16-row tile into registers one tile ahead (coalesced 16-byte loads, 1 KB per wave-instruction; ordinary loads, so the
+// compiler counts them), converts it -- the exact conversions of the reference, vcvtph2ps / vpmovsxbd + vcvtdq2ps
+// (src/simd_dot.cpp:102-124, 160-199) -- and writes it into an fp32 image of the tile in LDS; all four waves then feed their
+// MFMAs from the image with ds_read_b128 and immediate offsets, exactly like fp32 rows.  A quarter of the conversions, none
+// of them inside the MFMA stream.
+//   per tile and wave:  [192 MFMAs on image[t % 2]] -> [epilogue] -> [convert my quarter of tile t+1 into image[(t+1) % 2];
+//                        fetch my quarter of tile t+2] -> s_barrier
+//   image layout: row r at r * DIM * 4, 16-byte chunk p at position p ^ (r & 15) (the fp32-row build's, conflict-free for the
+//   A-operand reads); the conversion writes its 2 (fp16) / 4 (int8) chunks per raw chunk in a rotated order so that the 16
+//   lanes of a write phase fall into 16 different bank groups.
+//   LDS at d = 768: 2 x 48 KB image (+ 32 KB of top-k lists in the scan build).
+// Same chains, same order: bit-identical to every other exact kernel (test_exact_scores_on_the_fp32_matrix_cores).
+// ================================================================================================
+template <int DT, int DIM> constexpr bool exact_img_shape() { return DT != DT_F32 && (16 * DIM * exact_bpe<DT>()) % 4096 == 0; }   // whole 1-KB pieces per wave
+template <int DT, int DIM> constexpr int exact_img_bytes() { return 2 * 16 * DIM * 4; }
+
+template <int DT, int DIM, bool SCORES>
+__global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
+    const void* __restrict__ rows, const float* __restrict__ scales, uint32_t row_lo, uint32_t row_hi,
+    const float* __restrict__ q32, uint32_t nq, uint32_t k, const float* __restrict__ thr,
+    Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t* __restrict__ overflow,
+    float* __restrict__ out, uint64_t ld) {
+  static_assert(DT != DT_F32 && DIM % 32 == 0 && DIM <= 768 && exact_img_shape<DT, DIM>(), "fp16 / int8 rows; whole 1-KB pieces per wave");
+  constexpr int BPE = exact_bpe<DT>(), T = DIM / 32, ROW_BYTES = DIM * BPE, CHUNKS_PER_ROW = ROW_BYTES / 16;
+  constexpr int IMG_ROW = DIM * 4, IMG_BYTES = 16 * IMG_ROW;
+  constexpr int PIECES = 16 * ROW_BYTES / 1024, PPW = PIECES / 4;                   // 16-byte raw chunks per lane and tile
+  constexpr int RING = 4;                                                          // K-steps of LDS reads in flight
+  constexpr int EPC = 16 / BPE;                                                    // elements per raw chunk: 8 halves / 16 bytes
+  constexpr int WPC = EPC / 4;                                                     // fp32 chunks per raw chunk: 2 / 4
+  extern __shared__ __attribute__((aligned(16))) char smem[];                      // [image 0 | image 1]
+  __shared__ float l_s[SCORES ? 1 : 4][SCORES ? 1 : EXACT_MFMA_QB][64];
+  __shared__ uint32_t l_id[SCORES ? 1 : 4][SCORES ? 1 : EXACT_MFMA_QB][64];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x15 = lane & 15, kq = lane >> 4;
+  const uint32_t qg0 = blockIdx.y * 64u;
+  const uint32_t qi = qg0 + wave * EXACT_MFMA_QB + x15;          // < nq: full groups only
+
+  float bq[T][8];
+  exact_load_bq<DIM>(q32, qi, nq, kq, bq);
+  const float gthr = (!SCORES && thr != nullptr) ? thr[qi] : NEG_INF;
+
+  const uint32_t P = gridDim.x, p = blockIdx.x;
+  const uint32_t tiles = (row_hi - row_lo + EXACT_MFMA_ROWS - 1) / EXACT_MFMA_ROWS;
+  const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * p / P), t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * (p + 1) / P);
+  if (t_lo >= t_hi) return;
+
+  // my quarter of a tile: raw chunk i of this lane = linear chunk L = (wave * PPW + i) * 64 + lane = chunk L % CHUNKS_PER_ROW of
+  // row L / CHUNKS_PER_ROW; its fp32 values are the image chunks WPC * c + j, j < WPC, of that row
+  const char* gbase = static_cast<const char*>(rows);
+  // ONE register set, one tile (2.7 us) of prefetch distance.  A second set (the quarter of tile t+2 in flight while t+1 waits to be
+  // converted) was built and measured: 94.8 instead of 99.0 TFLOP/s at 256 queries, 75.4 instead of 78.5 at 64 -- the extra 24
+  // registers cost more than the deeper prefetch gains (profiles/r04_exact_img_bench.txt), so a single group of 64 queries,
+  // whose rows come from HBM rather than from the L2 the other groups' workgroups fill, stays at ~78.
+  uint4 rawreg[1][PPW];
+  float sc_nxt[1][4] = {{1.f, 1.f, 1.f, 1.f}};
+  auto fetch_tile = [&](uint32_t tile, auto SETC) {                // (a tile beyond my range: the last one again, never converted)
+    constexpr int SET = decltype(SETC)::value;
+    const uint32_t tl = tile < t_hi ? tile : t_hi - 1;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const uint32_t L = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
+      uint32_t r = row_lo + tl * EXACT_MFMA_ROWS + L / CHUNKS_PER_ROW;
+      r = r < row_hi ? r : row_hi - 1;
+      rawreg[SET][i] = *reinterpret_cast<const uint4*>(gbase + static_cast<uint64_t>(r) * ROW_BYTES + ((L % CHUNKS_PER_ROW) << 4));
+    }
+    if constexpr (DT == DT_I8) {
+      const uint32_t r0 = row_lo + tl * EXACT_MFMA_ROWS + 4u * static_cast<uint32_t>(kq);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sc_nxt[SET][v] = scales[r0 + v < row_hi ? r0 + v : row_hi - 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);                             // issued HERE, a whole tile ahead of their use
+  };
+  auto convert_tile = [&](uint32_t tile, auto SETC) {
+    constexpr int SET = decltype(SETC)::value;
+    char* img = smem + (tile & 1u) * IMG_BYTES;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const uint32_t L = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
+      const uint32_t r = L / CHUNKS_PER_ROW, c = L % CHUNKS_PER_ROW;
+      float x[EPC];
+      if constexpr (DT == DT_F16) {
+        ExactRaw<DT_F16> rw; rw.v = rawreg[SET][i];
+        exact_raw_to_f32<DT_F16>(rw, x);
+      } else {
+        ExactRaw<DT_I8> lo, hi; lo.v = make_uint2(rawreg[SET][i].x, rawreg[SET][i].y); hi.v = make_uint2(rawreg[SET][i].z, rawreg[SET][i].w);
+        float xl[8], xh[8];
+        exact_raw_to_f32<DT_I8>(lo, xl); exact_raw_to_f32<DT_I8>(hi, xh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[e] = xl[e]; x[8 + e] = xh[e]; }
+      }
+      // written in the order j = (rot + u) % WPC: the 16 consecutive raw chunks of one write phase then cover 16 different
+      // residues of the chunk position mod 16 (2c + (c >> 3 & 1) for fp16, 4c + (c >> 2 & 3) for int8)
+      const uint32_t rot = (WPC == 2) ? ((c >> 3) & 1u) : ((c >> 2) & 3u);
+#pragma unroll
+      for (int u = 0; u < WPC; ++u) {
+        const uint32_t j = (rot + u) & (WPC - 1);
+        float4 w = make_float4(x[0], x[1], x[2], x[3]);
+#pragma unroll
+        for (int jj = 1; jj < WPC; ++jj) if (j == static_cast<uint32_t>(jj)) w = make_float4(x[4 * jj], x[4 * jj + 1], x[4 * jj + 2], x[4 * jj + 3]);
+        const uint32_t pos = (WPC * c + j) ^ (r & 15u);
+        *reinterpret_cast<float4*>(img + r * IMG_ROW + (pos << 4)) = w;
+      }
+    }
+  };
+
+  // A-operand reads out of the image: chunks 8t + 2kq, + 1 of row x15 at position ^ x15 (the fp32-row build's addressing:
+  // two base registers plus immediates)
+  const uint32_t row_off = static_cast<uint32_t>(x15) * IMG_ROW;
+  const uint32_t a0 = row_off + (((2u * kq) ^ static_cast<uint32_t>(x15)) << 4);
+  const uint32_t a1 = row_off + (((2u * kq + 1u) ^ static_cast<uint32_t>(x15)) << 4);
+  auto read_step = [&](const char* img, int t) -> ExactRaw<DT_F32> {
+    ExactRaw<DT_F32> r;
+    r.a = *reinterpret_cast<const float4*>(img + (a0 ^ ((t & 1) << 7)) + (t >> 1) * 256);
+    r.b = *reinterpret_cast<const float4*>(img + (a1 ^ ((t & 1) << 7)) + (t >> 1) * 256);
+    return r;
+  };
+
+  float thr_s = NEG_INF;
+  uint32_t thr_id = 0xFFFFFFFFu, my_cnt = 0;
+  float sc_cur[4] = {1.f, 1.f, 1.f, 1.f};
+
+  // prologue: image of the first tile; my quarter of the second on its way
+  using S0 = std::integral_constant<int, 0>;
+  fetch_tile(t_lo, S0{});
+  convert_tile(t_lo, S0{});
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sc_cur[v] = sc_nxt[0][v];
+  fetch_tile(t_lo + 1, S0{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // my image writes have been performed before I signal
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // one tile: MFMAs out of image tile & 1, epilogue, then my quarter of tile + 1 (in registers since the previous iteration) ->
+  // the other image, and tile + 2 is fetched into the registers just freed
+  auto one_tile = [&](uint32_t tile, auto NEXTSET) {
+    const char* img = smem + (tile & 1u) * IMG_BYTES;
+    ExactRaw<DT_F32> ring[RING];
+#pragma unroll
+    for (int t = 0; t < RING - 1; ++t) ring[t] = read_step(img, t);
+    floatx4_t acc[8];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + RING - 1 < T) ring[(t + RING - 1) % RING] = read_step(img, t + RING - 1);
+      float x[8];
+      exact_raw_to_f32<DT_F32>(ring[t % RING], x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (t == 0) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], bq[0][j], floatx4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], bq[t][j], acc[j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float s[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float s0 = acc[0][v] + acc[4][v], s1 = acc[1][v] + acc[5][v], s2 = acc[2][v] + acc[6][v], s3 = acc[3][v] + acc[7][v];
+      s[v] = (s0 + s1) + (s2 + s3);
+    }
+    const uint32_t row0 = row_lo + tile * EXACT_MFMA_ROWS + 4u * static_cast<uint32_t>(kq);
+    if constexpr (DT == DT_I8) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) s[v] *= sc_cur[v];                               // simd_dot.cpp:198
+    }
+    if constexpr (SCORES) {
+      float* o = out + static_cast<uint64_t>(qi) * ld + row0;
+      if (row0 + 3 < row_hi) *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
+      else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) if (row0 + v < row_hi) o[v] = s[v];
+      }
+    } else {
+      bool pass[4];
+      bool any = false;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const uint32_t row = row0 + v;
+        pass[v] = row < row_hi && s[v] >= gthr && (my_cnt < k || better(s[v], row, thr_s, thr_id));
+        any = any || pass[v];
+      }
+      if (__ballot(any)) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          unsigned long long m = __ballot(pass[v]);
+          while (m) {
+            const int L = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t g = static_cast<uint32_t>(L) & 15u;
+            const float cs = readlane_f(s[v], L);
+            const uint32_t cid = row_lo + tile * EXACT_MFMA_ROWS + 4u * (static_cast<uint32_t>(L) >> 4) + v;
+            const uint32_t c = readlane_u(my_cnt, static_cast<int>(g));
+            const float ts = readlane_f(thr_s, static_cast<int>(g));
+            const uint32_t tid = readlane_u(thr_id, static_cast<int>(g));
+            if (!(c < k || better(cs, cid, ts, tid))) continue;
+            float es = l_s[SCORES ? 0 : wave][SCORES ? 0 : g][lane];
+            uint32_t eid = l_id[SCORES ? 0 : wave][SCORES ? 0 : g][lane];
+            const bool ahead = static_cast<uint32_t>(lane) < c && better(es, eid, cs, cid);
+            const uint32_t pos = static_cast<uint32_t>(__builtin_popcountll(__ballot(ahead)));
+            const float up_s = __shfl_up(es, 1);
+            const uint32_t up_id = __shfl_up(eid, 1);
+            if (static_cast<uint32_t>(lane) > pos) { es = up_s; eid = up_id; }
+            else if (static_cast<uint32_t>(lane) == pos) { es = cs; eid = cid; }
+            const uint32_t c2 = c < k ? c + 1 : k;
+            if (static_cast<uint32_t>(lane) < c2) { l_s[SCORES ? 0 : wave][SCORES ? 0 : g][lane] = es; l_id[SCORES ? 0 : wave][SCORES ? 0 : g][lane] = eid; }
+            const float nts = readlane_f(es, static_cast<int>(k) - 1);
+            const uint32_t ntid = readlane_u(eid, static_cast<int>(k) - 1);
+            if (static_cast<uint32_t>(x15) == g) {
+              my_cnt = c2;
+              if (c2 == k) { thr_s = nts; thr_id = ntid; }
+            }
+          }
+        }
+      }
+    }
+    if (tile + 1 < t_hi) {
+      convert_tile(tile + 1, NEXTSET);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sc_cur[v] = sc_nxt[decltype(NEXTSET)::value][v];
+      fetch_tile(tile + 2, NEXTSET);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // image (tile + 1) & 1 complete; everybody is done reading image tile & 1
+    asm volatile("" ::: "memory");
+  };
+  for (uint32_t tile = t_lo; tile < t_hi; ++tile) one_tile(tile, S0{});
   if constexpr (!SCORES) {
     for (uint32_t g = 0; g < EXACT_MFMA_QB; ++g) {
       const uint32_t q = qg0 + wave * EXACT_MFMA_QB + g;

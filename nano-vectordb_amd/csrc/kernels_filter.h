@@ -51,19 +51,54 @@ constexpr int FILTER_STAGES_I8 = 5;      // int8 stages are half the bytes: 5 st
 //   slack[q]   = 2 * ebound[q]
 // grid = nq_pad (multiple of 256), block = 256.  Pad queries get zeros.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim, uint32_t sdim,
+// What init_search_kernel resets per search, folded into the prep launch of the filter path (one launch fewer per search; the
+// exact and any-k paths have no prep kernel and keep init_search_kernel).  cnt == nullptr: nothing.  q_src != nullptr: the
+// queries are read from THERE (pinned host memory the device reads over PCIe: the host API's small calls enqueue no H2D copy)
+// and written to the search's device copy `q32`, which every later kernel reads.
+struct PrepInit {
+  uint32_t* cnt;
+  float* thr;
+  uint32_t* misc;
+  uint32_t* prog;
+  uint32_t prog_words;
+  uint32_t* tickets;               // FUSE_TICKETS words: "last workgroup" ticket of the fused rescore + final select launch
+  const float* q_src;
+  float* q32_copy;
+};
+constexpr uint32_t FUSE_TICKETS = 1;
+
+// block q of the prep grid (nq_pad blocks): its own query's words; the shared words strided over the grid.  Returns where the block
+// reads its query from.
+__device__ __forceinline__ const float* prep_init(const PrepInit& pi, const float* q32, uint32_t q, uint32_t tid, uint32_t nq, uint32_t dim, uint32_t* overflow) {
+  if (pi.cnt != nullptr) {
+    if (tid == 0) { pi.cnt[q] = 0; overflow[q] = 0; pi.thr[q] = NEG_INF; }
+    if (q == 0 && tid < 8) pi.misc[tid] = 0;
+    if (q == 0 && tid >= 64 && tid < 64 + FUSE_TICKETS) pi.tickets[tid - 64] = 0;
+    for (uint32_t j = q * 256 + tid; j < pi.prog_words; j += gridDim.x * 256) pi.prog[j] = 0xFFFFFFFFu;
+  }
+  if (pi.q_src != nullptr && q < nq) {
+    // each thread later re-reads exactly the elements it copies here (same stride): its own global writes, always visible to it
+    float* dst = pi.q32_copy + static_cast<uint64_t>(q) * dim;
+    const float* srch = pi.q_src + static_cast<uint64_t>(q) * dim;
+    for (uint32_t i = tid; i < dim; i += 256) dst[i] = srch[i];
+    return dst;
+  }
+  return q32 + static_cast<uint64_t>(q) * dim;
+}
+
+static __global__ __launch_bounds__(256) void prep_q16_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim, uint32_t sdim,
                                                        float max_row_norm, float rel, float abs_per_norm, uint32_t* __restrict__ overflow, _Float16* __restrict__ q16,
                                                        float* __restrict__ qscale, float* __restrict__ qinv,
-                                                       float* __restrict__ ebound, float* __restrict__ slack) {
+                                                       float* __restrict__ ebound, float* __restrict__ slack, PrepInit pi) {
   __shared__ float red_max[4], red_ss[4];
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const float* src = prep_init(pi, q32, q, tid, nq, dim, overflow);
   // sdim >= dim: row stride of q16 = the (zero-padded) dim the filter kernel is instantiated for
   if (q >= nq) {
     for (uint32_t i = tid; i < sdim; i += 256) q16[static_cast<uint64_t>(q) * sdim + i] = static_cast<_Float16>(0.f);
     if (tid == 0) { qscale[q] = 1.f; qinv[q] = 1.f; ebound[q] = 0.f; slack[q] = 0.f; }
     return;
   }
-  const float* src = q32 + static_cast<uint64_t>(q) * dim;
   float mx = 0.f, ss = 0.f;
   for (uint32_t i = tid; i < dim; i += 256) { const float v = src[i]; mx = fmaxf(mx, fabsf(v)); ss = __builtin_fmaf(v, v, ss); }
   for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); ss += __shfl_xor(ss, o); }
@@ -916,21 +951,21 @@ __global__ __launch_bounds__(256, 1) void filter_f16_k2_kernel(
 // into the wave's own LDS slot, so that no ordinary global load -- whose compiler-inserted vmcnt wait
 // would drain the stream -- is needed in the loop).
 // ================================================================================================
-__global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim, uint32_t sdim,
+static __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim, uint32_t sdim,
                                                       float max_row_norm, signed char* __restrict__ qhi,
                                                       signed char* __restrict__ qlo, float* __restrict__ qscale,
                                                       float* __restrict__ qinv, float* __restrict__ ebound,
-                                                      float* __restrict__ slack, float* __restrict__ qdelta, uint32_t* __restrict__ overflow, uint32_t lo_bits) {
+                                                      float* __restrict__ slack, float* __restrict__ qdelta, uint32_t* __restrict__ overflow, uint32_t lo_bits, PrepInit pi) {
   __shared__ float red_max[4], red_ss[4];
   __shared__ uint32_t red_lo[4];
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const float* src = prep_init(pi, q32, q, tid, nq, dim, overflow);
   // sdim >= dim: row stride of the two planes = the (zero-padded) dim the filter kernel is instantiated for
   if (q >= nq) {
     for (uint32_t i = tid; i < sdim; i += 256) { qhi[static_cast<uint64_t>(q) * sdim + i] = 0; qlo[static_cast<uint64_t>(q) * sdim + i] = 0; }
     if (tid == 0) { qscale[q] = 1.f; qinv[q] = 1.f; ebound[q] = 0.f; slack[q] = 0.f; qdelta[q] = 0.f; }
     return;
   }
-  const float* src = q32 + static_cast<uint64_t>(q) * dim;
   float mx = 0.f, ss = 0.f;
   for (uint32_t i = tid; i < dim; i += 256) { const float v = src[i]; mx = fmaxf(mx, fabsf(v)); ss = __builtin_fmaf(v, v, ss); }
   for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); ss += __shfl_xor(ss, o); }
@@ -2125,99 +2160,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void filter_i8p_kernel(
   if (wave == 0 && lane == 0) record_xcd_speed(sa.xcdw, xcd_map, stream & 7u, NT, static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime()) - xw_t0);
   if constexpr (DEFER) scatter_own_log(mylog, wcnt, sa, lane);
   else verify_and_scatter_i8<DIM>(mylog, wcnt, sa, lane, rows, qlo, thr, qscale, qinv);
-}
-
-// ------------------------------------------------------------------------------------------------
-// synthetic corpus generator: one wave per row (bit-identical to nvdb_synth_rows_f32 on the host
-// followed by the RNE half conversion / the reference's int8 quantiser).
-// ------------------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(256) void gen_rows_kernel(uint64_t seed, uint64_t row_base, uint64_t n, uint32_t dim,
-                                                       void* __restrict__ rows, float* __restrict__ scales) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t r = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (r >= n) return;
-  const uint32_t key = synth_row_key(seed, row_base + r);
-  unsigned long long ss = 0;
-  for (uint32_t c = lane; c < dim; c += 64) { const long long v = synth_raw(key, c); ss += static_cast<unsigned long long>(v * v); }
-  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const double inv = synth_inv_norm(ss);
-  if constexpr (DT == DT_F32) {
-    float* out = static_cast<float*>(rows) + r * dim;
-    for (uint32_t c = lane; c < dim; c += 64) out[c] = synth_elem(synth_raw(key, c), inv);
-  } else if constexpr (DT == DT_F16) {
-    _Float16* out = static_cast<_Float16*>(rows) + r * dim;
-    for (uint32_t c = lane; c < dim; c += 64) out[c] = static_cast<_Float16>(synth_elem(synth_raw(key, c), inv));
-  } else {
-    float mx = 0.f;
-    for (uint32_t c = lane; c < dim; c += 64) mx = fmaxf(mx, fabsf(synth_elem(synth_raw(key, c), inv)));
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    const float scale = mx > 0.f ? mx / 127.f : 1.f;
-    const float is = 1.0f / scale;
-    signed char* out = static_cast<signed char*>(rows) + r * dim;
-    for (uint32_t c = lane; c < dim; c += 64) {
-      float qv = rintf(synth_elem(synth_raw(key, c), inv) * is);
-      qv = fminf(fmaxf(qv, -127.f), 127.f);
-      out[c] = static_cast<signed char>(static_cast<int>(qv));
-    }
-    if (lane == 0) scales[r] = scale;
-  }
-}
-
-// "shadow" copy streamed by the MFMA filter when the corpus itself cannot be: an fp32 corpus (rounded to fp16,
-// round-to-nearest-even) and/or a dim the kernels are not instantiated for (rows zero-padded to sdim).  Also
-// returns max |x| (float bits via atomicMax).  The original rows stay the arbiter: every survivor is re-scored
-// from them in the reference's order.
-template <typename SrcT>
-__global__ __launch_bounds__(256) void shadow_f16_kernel(const SrcT* __restrict__ src, _Float16* __restrict__ dst, size_t n,
-                                                         uint32_t dim, uint32_t sdim, uint32_t* __restrict__ maxabs_bits) {
-  float mx = 0.f;
-  const size_t count = n * sdim;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<size_t>(gridDim.x) * 256) {
-    const size_t r = i / sdim;
-    const uint32_t c = static_cast<uint32_t>(i - r * sdim);
-    const float v = c < dim ? static_cast<float>(src[r * dim + c]) : 0.f;
-    dst[i] = static_cast<_Float16>(v);
-    mx = fmaxf(mx, fabsf(v));
-  }
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(maxabs_bits, __builtin_bit_cast(uint32_t, mx));
-}
-
-// int8 corpus whose dim the kernels are not instantiated for: copy with rows zero-padded to sdim bytes (the swizzled LDS image
-// needs a row stride that is a multiple of 128 bytes, swz_chunk); 16 source bytes per thread where alignment allows
-__global__ __launch_bounds__(256) void shadow_i8_kernel(const signed char* __restrict__ src, signed char* __restrict__ dst, size_t n,
-                                                        uint32_t dim, uint32_t sdim) {
-  const size_t count = n * sdim;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<size_t>(gridDim.x) * 256) {
-    const size_t r = i / sdim;
-    const uint32_t c = static_cast<uint32_t>(i - r * sdim);
-    dst[i] = c < dim ? src[r * dim + c] : static_cast<signed char>(0);
-  }
-}
-
-// max over rows of the (dequantised) L2 norm, slightly inflated; result as float bits via atomicMax
-template <int DT>
-__global__ __launch_bounds__(256) void row_norm_max_kernel(const void* __restrict__ rows, const float* __restrict__ scales,
-                                                           uint64_t n, uint32_t dim, uint32_t* __restrict__ out_bits) {
-  const int lane = threadIdx.x & 63;
-  float wmax = 0.f;
-  for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); r < n; r += static_cast<uint64_t>(gridDim.x) * 4) {
-    const void* rp = row_ptr<DT>(rows, r, dim);
-    float ss = 0.f;
-    for (uint32_t c = lane; c < dim; c += 64) { const float v = load1<DT>(rp, c); ss = __builtin_fmaf(v, v, ss); }
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    float nrm = sqrtf(ss) * 1.0001f;
-    if constexpr (DT == DT_I8) {
-      const float sc = scales[r];
-      nrm *= fabsf(sc);
-      // a negative / NaN row scale, or one so large that 2^23 * scale overflows (inf - inf = NaN would lose the flag silently):
-      // the biased-accumulator test assumes neither -> such corpora take the in-loop (unbiased) build
-      if (!(sc >= 0.f && sc < 1e30f) && lane == 0) out_bits[1] = 1u;
-    }
-    wmax = fmaxf(wmax, nrm);
-  }
-  if (lane == 0 && wmax > 0.f) atomicMax(out_bits, __builtin_bit_cast(uint32_t, wmax));
 }
 
 }  // namespace nvdbhip

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void scores_exact_kernel(const void* __restric
 struct RadixState { unsigned long long prefix; uint32_t krem; uint32_t taken; };
 
 // pass p (0..7): histogram of byte (7-p) of the keys whose top p bytes equal the prefix.  grid = (G, nq), block 256.
-__global__ __launch_bounds__(256) void radix_hist_kernel(const float* __restrict__ scores, uint64_t ld, uint32_t n, int pass,
+static __global__ __launch_bounds__(256) void radix_hist_kernel(const float* __restrict__ scores, uint64_t ld, uint32_t n, int pass,
                                                          const RadixState* __restrict__ st, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[256];
   const uint32_t q = blockIdx.y;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const float* __restrict
 }
 
 // grid = nq, block = 256: the digit that holds the krem-th largest key of this pass; clears the histogram for the next.
-__global__ __launch_bounds__(256) void radix_pick_kernel(RadixState* __restrict__ st, uint32_t* __restrict__ hist) {
+static __global__ __launch_bounds__(256) void radix_pick_kernel(RadixState* __restrict__ st, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[256];
   __shared__ uint32_t above[256];
   const uint32_t q = blockIdx.x, d = threadIdx.x;
@@ -105,14 +105,14 @@ __global__ __launch_bounds__(256) void radix_pick_kernel(RadixState* __restrict_
   }
 }
 
-__global__ void radix_init_kernel(RadixState* __restrict__ st, uint32_t* __restrict__ hist, uint32_t nq, uint32_t k) {
+static __global__ void radix_init_kernel(RadixState* __restrict__ st, uint32_t* __restrict__ hist, uint32_t nq, uint32_t k) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < nq) { st[i].prefix = 0; st[i].krem = k; st[i].taken = 0; }
   if (i < nq * 256u) hist[i] = 0;
 }
 
 // sel[q][0..k) = every key >= the k-th largest (after pass 7 the prefix IS that key); slots >= k up to K2 are padding 0
-__global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ scores, uint64_t ld, uint32_t n, RadixState* __restrict__ st,
+static __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ scores, uint64_t ld, uint32_t n, RadixState* __restrict__ st,
                                                       unsigned long long* __restrict__ sel, uint32_t K2, uint32_t k) {
   const uint32_t q = blockIdx.y;
   const unsigned long long kth = st[q].prefix;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void collect_kernel(const float* __restrict__ 
 }
 
 // descending bitonic sort of K2 (power of two, <= 8192) keys per query in LDS.  grid = nq, block = 256, LDS = K2 * 8.
-__global__ __launch_bounds__(256) void bitonic_lds_kernel(unsigned long long* __restrict__ sel, uint32_t K2) {
+static __global__ __launch_bounds__(256) void bitonic_lds_kernel(unsigned long long* __restrict__ sel, uint32_t K2) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned long long* e = reinterpret_cast<unsigned long long*>(smem_raw);
   unsigned long long* mine = sel + static_cast<uint64_t>(blockIdx.x) * K2;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void bitonic_lds_kernel(unsigned long long* __
 }
 
 // one compare-exchange step of the same network in global memory (K2 > 8192).  grid = (K2 / 512, nq), block = 256.
-__global__ __launch_bounds__(256) void bitonic_global_step_kernel(unsigned long long* __restrict__ sel, uint32_t K2, uint32_t size, uint32_t stride) {
+static __global__ __launch_bounds__(256) void bitonic_global_step_kernel(unsigned long long* __restrict__ sel, uint32_t K2, uint32_t size, uint32_t stride) {
   unsigned long long* mine = sel + static_cast<uint64_t>(blockIdx.y) * K2;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= (K2 >> 1)) return;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void bitonic_global_step_kernel(unsigned long 
 }
 
 // out[q][j] for j < out_k: the j-th key's row (global id) and the score's original bits; j >= k_eff padded
-__global__ __launch_bounds__(256) void emit_kernel(const unsigned long long* __restrict__ sel, uint32_t K2, const float* __restrict__ scores, uint64_t ld,
+static __global__ __launch_bounds__(256) void emit_kernel(const unsigned long long* __restrict__ sel, uint32_t K2, const float* __restrict__ scores, uint64_t ld,
                                                    uint32_t k_eff, uint32_t out_k, uint64_t row_base, unsigned long long* __restrict__ out_ids,
                                                    float* __restrict__ out_scores) {
   const uint32_t q = blockIdx.y;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const unsigned long long* __r
 
 // the same keys into the filter path's candidate lists instead (exact bootstrap of a wide-k search, search_core): entry j of
 // query q = (exact score, row inside the shard); cnt[q] = k
-__global__ __launch_bounds__(256) void seed_lists_kernel(const unsigned long long* __restrict__ sel, uint32_t K2, const float* __restrict__ scores, uint64_t ld,
+static __global__ __launch_bounds__(256) void seed_lists_kernel(const unsigned long long* __restrict__ sel, uint32_t K2, const float* __restrict__ scores, uint64_t ld,
                                                          uint32_t k, Cand* __restrict__ cand, uint32_t cap, uint32_t* __restrict__ cnt) {
   const uint32_t q = blockIdx.y;
   const uint32_t j = blockIdx.x * 256u + threadIdx.x;

@@ -27,7 +27,9 @@
 #include <thread>
 #include <vector>
 
+#pragma GCC visibility push(default)
 #include "../../include/nvdb_hip.h"
+#pragma GCC visibility pop
 
 namespace {
 

@@ -1,0 +1,537 @@
+// nvdb_search.cpp -- orchestration of one flat search (DESIGN.md "pipeline") and the search entry points of the C ABI:
+//   path 1 (exact):   init -> exact scan over the whole corpus -> select(final)
+//   path 2 (filter):  prep (+ init) -> bootstrap (+ select) -> { filter launch on a chunk (+ select) }* with growing chunks
+//                     -> rescore in the reference's fp32 order + final select
+//   path 3 (any k):   score matrix of a query sub-batch -> radix select -> sort
+// No kernel is defined or launched from this file: the launch helpers live in nvdb_launch_*.cpp.
+#include "nvdb_ctx.h"
+
+namespace nvdbhip {
+
+// The host API's result block: the 64 bytes of status words (c->misc points INTO the block from then on), ids, scores -- one
+// allocation, so that one copy brings down everything a search's caller waits for.  Growing it carries the status words
+// (the sticky ones outlive a search) over to the new allocation.
+nvdb_status ensure_hostblock(nvdb_hip_ctx* c, size_t out_bytes) {
+  const size_t need = 64 + out_bytes;
+  if (c->hostblock.p && c->hostblock.bytes >= need) return NVDB_OK;
+  HIPCHK(c, hipDeviceSynchronize());
+  void* np = nullptr;
+  const size_t want = std::max<size_t>(need + need / 2, static_cast<size_t>(1) << 20);
+  HIPCHK(c, hipMalloc(&np, want));
+  if (c->misc.p) HIPCHK(c, hipMemcpy(np, c->misc.p, 64, hipMemcpyDeviceToDevice));
+  else HIPCHK(c, hipMemset(np, 0, 64));
+  if (c->hostblock.p) HIPCHK(c, hipFree(c->hostblock.p));
+  else if (c->misc.p) HIPCHK(c, hipFree(c->misc.p));
+  c->hostblock.p = np; c->hostblock.bytes = want;
+  c->misc.p = np; c->misc.bytes = 64;
+  return NVDB_OK;
+}
+
+// rendezvous counters for the next filter launch: a region the init kernel already cleared, or (past PROG_SLOTS
+// launches in one search) a region cleared here
+nvdb_status next_prog_region(nvdb_hip_ctx* c, hipStream_t s, uint32_t nwg, uint32_t** out) {
+  const size_t region_words = static_cast<size_t>(c->num_cu) * 8;
+  if (nwg * 8u > region_words) return fail(c, NVDB_ERR_INTERNAL, "rendezvous region too small for this grid");
+  uint32_t* base = static_cast<uint32_t*>(c->prog.p) + static_cast<size_t>(c->prog_slot % PROG_SLOTS) * region_words;
+  if (c->prog_slot >= PROG_SLOTS) HIPCHK(c, hipMemsetAsync(base, 0xFF, region_words * 4, s));
+  ++c->prog_slot;
+  *out = base;
+  return NVDB_OK;
+}
+
+// trows = rows per tile of the kernel being launched (0: identity tile order).  With the permutation on, logical tile g
+// of the corpus' T = ceil-or-floor(n / trows) tiles is streamed from physical tile perm_tile(g) (kernels_filter.h).
+ScatterArgs scatter_args(nvdb_hip_ctx* c, uint32_t cap, uint32_t trows) {
+  ScatterArgs a{static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), static_cast<uint32_t*>(c->overflow.p),
+                static_cast<uint32_t*>(c->misc.p) + 1, cap, static_cast<uint32_t>(c->n), 1u, 0u, 0u,
+                c->opt_xcd_balance ? static_cast<float*>(c->xcdw.p) : nullptr, static_cast<uint32_t>(c->opt_i8_lo_bits)};
+  if (trows && c->perm_on) {
+    const bool padded = c->owned || c->shadow16 != nullptr || c->shadow8 != nullptr;
+    const uint32_t n = static_cast<uint32_t>(c->n);
+    const uint32_t T = padded ? (n + trows - 1) / trows : n / trows;
+    perm_params(T, a.perm_mul, a.perm_mask);
+    a.perm_T = T;
+  }
+  return a;
+}
+
+nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap, uint32_t nb) {
+  // (int8: the boot build is the 128-queries-per-workgroup kernel; same padded batch)
+  return c->dtype == NVDB_DTYPE_I8 ? launch_boot_i8(c, s, n0, nq, QT * nb, cap) : launch_boot_f16(c, s, n0, nq, QT, cap, nb);
+}
+
+nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT, uint32_t cap) {
+  return c->dtype == NVDB_DTYPE_I8 ? launch_filter_i8(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_f16(c, s, row_lo, row_hi, nq, QT, cap);
+}
+
+// Enqueue one whole search of nq (<= 2048) queries resident at dev_q.  No host synchronisation.
+// host_q != nullptr (host API, small calls): the queries are still in pinned host memory at host_q and `dev_q` is the device
+// buffer they belong in -- the filter path's prep launch reads them over PCIe and fills dev_q itself, every other path gets a
+// copy enqueued here.  status_out != nullptr: pinned host memory for the 8 status words; c->status_by_kernel tells the caller
+// whether the search's last kernel wrote them (else it copies misc itself).
+nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint32_t nq, uint32_t k, uint64_t* dev_out_ids,
+                        float* dev_out_scores, int force_path, bool time_filter, uint32_t cap_override = 0, bool sticky = true,
+                        const float* host_q = nullptr, uint32_t* status_out = nullptr) {
+  c->status_by_kernel = false;
+  const int final_mode = sticky ? 1 : 3;          // select_kernel: 3 = final select without folding into the sticky self-check words
+  const uint32_t k_eff = static_cast<uint32_t>(std::min<uint64_t>(k, c->n));
+  const uint32_t n = static_cast<uint32_t>(c->n);
+  int path = force_path ? force_path : static_cast<int>(c->opt_path);
+  if (path == 0) path = (filter_supported(c) && nq >= c->opt_min_filter_batch && c->n >= 4ull * c->opt_chunk0) ? 2 : 1;
+  if (path == 2 && !filter_supported(c)) return fail(c, NVDB_ERR_UNSUPPORTED, "MFMA filter path needs an fp16/fp32 corpus with dim <= 3072 or an int8 corpus with dim <= 1536");
+
+  uint32_t cap = cap_override ? cap_override : c->opt_cap > 0 ? static_cast<uint32_t>(c->opt_cap) : std::max<uint32_t>(c->cap_hint, nq <= 64 ? SELECT_MAX_CAP : 2048u);
+  cap = std::min(cap, SELECT_MAX_CAP);
+  if (cap < 4 * k_eff) cap = std::min<uint32_t>(SELECT_MAX_CAP, 4 * k_eff);
+  // 64 < k <= 1024 on the filter path (its kernels do not depend on k; the lists do): the longest lists, a bootstrap over
+  // 8k tile maxima and chunks small enough that k * (growth - 1) new survivors + the k kept ones + the error band fit.
+  // Anything else beyond the wavefront lists' 64 entries takes the any-k path.
+  const bool k_wide = k_eff > WAVE_KMAX;
+  // dims whose kernels have no MFMA bootstrap build (768 < dim): an EXACT bootstrap over the first 8k tiles' rows on the any-k
+  // machinery (score matrix of the sample -> radix select -> the k best seed the lists), then the filter streams the rest
+  const bool wide_exact_boot = k_wide && path == 2 && force_path != 1 && k_eff <= FILTER_KMAX && c->fdim > 768 &&
+                               c->n >= 4ull * FILTER_ROWS * 8 * k_eff;
+  const bool wide_on_filter = wide_exact_boot || (k_wide && path == 2 && force_path != 1 && k_eff <= FILTER_KMAX && c->opt_mfma_boot &&
+                              c->fdim <= 768 && c->n >= 2ull * FILTER_ROWS * 8 * k_eff);
+  if (wide_on_filter) cap = SELECT_MAX_CAP;
+  // queries per filter workgroup: 256 / 128, or 64 on the K-split build (dims > 1536)
+  const uint32_t QPB = (c->dtype != NVDB_DTYPE_I8 && c->fdim > 1536) ? 64u : 128u * filter_nb(c, nq);
+  const uint32_t QT = (nq + QPB - 1) / QPB;
+  const uint32_t nq_pad = QT * QPB;
+
+  nvdb_status st;
+  if ((st = ensure(c, c->thr, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->cnt, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->overflow, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->cand, static_cast<size_t>(nq) * cap * sizeof(Cand)))) return st;
+  if ((st = ensure(c, c->misc, 64))) return st;
+  // one region of sibling-rendezvous counters per filter launch of this search, all reset by the init kernel
+  const uint32_t prog_words = PROG_SLOTS * static_cast<uint32_t>(c->num_cu) * 8u;
+  if ((st = ensure(c, c->prog, static_cast<size_t>(prog_words) * 4))) return st;
+  c->prog_slot = 0;
+  if ((st = ensure(c, c->tickets, FUSE_TICKETS * 4))) return st;
+  // The filter path's prep launch does the per-search resets itself (and, for the host API's small calls, reads the queries
+  // straight from pinned host memory); the exact and any-k paths have no prep launch: init_search_kernel, queries copied here.
+  const bool filter_flow = path == 2 && !(k_wide && !wide_on_filter);
+  const bool prep_inits = c->opt_fuse && filter_flow;
+  if (host_q && !prep_inits) { HIPCHK(c, hipMemcpyAsync(const_cast<float*>(dev_q), host_q, static_cast<size_t>(nq) * c->dim * 4, hipMemcpyHostToDevice, s)); host_q = nullptr; }
+  // (one query tile per stream has no siblings to keep in step: nothing to reset)
+  if (!prep_inits) {
+    if ((st = launch_init_search(c, s, nq_pad, QT > 1 ? prog_words : 0u))) return st;
+  }
+  const PrepInit pinit = prep_inits ? PrepInit{static_cast<uint32_t*>(c->cnt.p), static_cast<float*>(c->thr.p), static_cast<uint32_t*>(c->misc.p),
+                                               static_cast<uint32_t*>(c->prog.p), QT > 1 ? prog_words : 0u, static_cast<uint32_t*>(c->tickets.p), host_q, const_cast<float*>(dev_q)}
+                                    : PrepInit{nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr};
+
+  c->stats = nvdb_hip_scan_stats{};
+  c->stats.path = static_cast<uint32_t>(path);
+  c->last_nq = nq; c->last_cap = cap; c->last_filter = (path == 2);
+  c->ev_filter.clear();
+
+  if (k_wide && !wide_on_filter) {
+    // beyond the wavefront-resident lists (k <= 64) and not on the filter path: the any-k path (scores -> radix select -> sort)
+    c->stats.path = 3; c->last_filter = false;
+    return search_largek(c, s, dev_q, nq, k, dev_out_ids, dev_out_scores);
+  }
+  if (path == 1) {
+    if ((st = launch_scan_exact(c, s, 0, n, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
+    c->stats.chunks = 1; c->stats.rows_scanned = c->n;
+    return launch_select(c, s, nq, cap, k_eff, nullptr, final_mode, dev_out_ids, dev_out_scores, k);
+  }
+
+  // ---- path 2: MFMA filter ----------------------------------------------------------------------
+  if ((st = ensure(c, c->q16, static_cast<size_t>(nq_pad) * c->fdim * 2))) return st;
+  if ((st = ensure(c, c->qscale, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->qinv, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->ebound, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->slack, nq_pad * 4))) return st;
+  if ((st = ensure(c, c->qdelta, nq_pad * 4))) return st;
+  if ((st = c->dtype == NVDB_DTYPE_I8 ? launch_prep_q8(c, s, dev_q, nq, nq_pad, pinit) : launch_prep_q16(c, s, dev_q, nq, nq_pad, pinit))) return st;
+  const float* slack = static_cast<const float*>(c->slack.p);
+  // Whole tiles: a corpus this library allocated is zero-padded to a multiple of 32 rows (the padded rows are
+  // dropped when the wave files its survivors); for an adopted corpus the ragged tail goes to the exact kernel.
+  const bool padded = c->owned || c->shadow16 != nullptr || c->shadow8 != nullptr;          // a shadow copy is always ours, hence padded
+  // chunk boundaries are whole tiles of the streaming kernel: 64 rows for the int8 two-stage kernel and for the m16
+  // fp16 build at d <= 384, 32 otherwise
+  const bool f16_wide_tiles = c->dtype != NVDB_DTYPE_I8 && c->fdim <= 384 && filter_nb(c, nq) == 2 && c->opt_mfma16;
+  const uint32_t tile_rows = ((i8_two_stage(c) && c->fdim <= 768) || f16_wide_tiles) ? I8W_TILE_ROWS : FILTER_ROWS;
+  const uint32_t n_al = padded ? (n + tile_rows - 1) / tile_rows * tile_rows : n / tile_rows * tile_rows;
+  uint32_t r = 0;
+  uint64_t size;
+  // chunk i covers (growth-1) x the rows seen before it.  fp16: 8 (flat between 4 and 8).  int8 batches > 128: 3 --
+  // tighter thresholds earlier mean fewer tiles for which the two-stage kernel needs the lo plane, and a tile costs
+  // what its slowest wave costs (profiles/r01d_i8_growth_sweep.txt)
+  // (with the first-stage survivors finished after the stream a flagged value costs little: 6 and a 1024-tile bootstrap on big
+  // corpora, profiles/r02_i8_boot_growth_sweep.txt; the in-loop second stage wants 3)
+  const bool i8_big = i8_two_stage(c) && nq > 128 && c->fdim <= 768;
+  const bool i8_log = i8_big && c->opt_i8_pipe && !c->opt_i8_defer && !c->i8_scales_signed && !c->opt_i8_waves8 && c->n >= 64ull * FILTER_ROWS * 1024;
+  uint64_t growth = c->opt_growth > 0 ? static_cast<uint64_t>(c->opt_growth) : (i8_log ? 6u : i8_big ? 3u : 8u);
+  if (k_wide) growth = std::max<uint64_t>(2, std::min<uint64_t>(growth, cap / (3ull * k_eff)));     // k * (growth - 1) + k + band <= cap
+  // T tile maxima with T >= 8k: their k-th largest is then close to the k-th best of the 32*T rows (with T == k it
+  // would be the smallest tile maximum, a uselessly weak threshold)
+  uint32_t boot_tiles = std::max<uint32_t>(64u, 8u * k_eff);
+  if (c->opt_boot_tiles > 0) boot_tiles = std::max<uint32_t>(boot_tiles, std::min<uint32_t>(static_cast<uint32_t>(c->opt_boot_tiles), cap));
+  else if (i8_log && !k_wide) boot_tiles = std::max<uint32_t>(boot_tiles, std::min<uint32_t>(1024u, cap));
+  const uint32_t boot_rows = FILTER_ROWS * boot_tiles;
+  const bool mfma_boot = c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
+                         boot_rows / FILTER_ROWS <= cap &&
+                         c->fdim <= 768;    // no bootstrap build of the 16-row-tile fp16 kernel / the 32-query int8 kernel: exact bootstrap chunk
+  if (k_wide && !mfma_boot && !wide_exact_boot) {
+    // 64 < k on the filter path needs the MFMA bootstrap (the exact bootstrap chunk's wavefront lists hold 64 entries);
+    // e.g. option boot_tiles larger than the corpus: the any-k path takes the search instead
+    c->stats.path = 3; c->last_filter = false;
+    return search_largek(c, s, dev_q, nq, k, dev_out_ids, dev_out_scores);
+  }
+  // permuted tile order needs the bootstrap whose entries are discarded (the exact bootstrap chunk keeps rows [0, r))
+  c->perm_on = c->opt_tile_permute && mfma_boot;
+  if (mfma_boot) {
+    // thresholds from the k-th largest of the 64 tile maxima of rows [0,2048); those rows are then scanned
+    // again by the normal build, so the bootstrap entries are discarded (select mode 2)
+    if ((st = launch_boot(c, s, boot_rows, nq, QT, cap, filter_nb(c, nq)))) return st;
+    if ((st = launch_select(c, s, nq, cap, k_eff, slack, 2, nullptr, nullptr, boot_rows / FILTER_ROWS))) return st;   // mode 2: out_k = list length
+    size = static_cast<uint64_t>(boot_rows) * growth;
+  } else {
+    // bootstrap chunk [0,r) on the exact kernel; r is a multiple of the 32-row MFMA tile
+    r = std::min<uint32_t>(n_al, (static_cast<uint32_t>(k_wide ? FILTER_ROWS * 8u * k_eff : c->opt_chunk0) + tile_rows - 1) / tile_rows * tile_rows);
+    if (r > n) r = n / tile_rows * tile_rows;
+    if (k_wide) { if ((st = search_largek(c, s, dev_q, nq, k_eff, nullptr, nullptr, r, static_cast<Cand*>(c->cand.p), static_cast<uint32_t*>(c->cnt.p), cap))) return st; }
+    else
+    if ((st = launch_scan_exact(c, s, 0, r, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
+    if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
+    size = static_cast<uint64_t>(r) * (growth - 1);
+  }
+  size_t ev = 0;
+  while (r < n_al) {
+    const uint32_t hi = static_cast<uint32_t>(std::min<uint64_t>(n_al, static_cast<uint64_t>(r) + size));
+    nvdb_hip_ctx::KLaunch kl{nullptr, nullptr, 0.0, 0.0};
+    const bool acct = c->opt_time_kernels && c->klaunch.size() < 8192;
+    if (acct) {
+      // the kernel's own start/stop timestamps (events attached to the launch itself: no barrier packets, no gaps)
+      for (hipEvent_t* e : {&kl.e0, &kl.e1}) {
+        if (!c->kl_pool.empty()) { *e = c->kl_pool.back(); c->kl_pool.pop_back(); }
+        else HIPCHK(c, hipEventCreate(e));
+      }
+      kl.flops = 2.0 * nq * static_cast<double>(std::min(hi, n) - r) * c->dim;   // algorithmic: real queries, real rows
+      kl.bytes = static_cast<double>(std::min(hi, n) - r) * (c->dtype == NVDB_DTYPE_I8 ? c->fdim + 4.0 : c->fdim * 2.0);   // rows streamed once
+      c->launch_e0 = kl.e0; c->launch_e1 = kl.e1;
+    } else if (time_filter) {
+      c->launch_e0 = get_event(c, ev); c->launch_e1 = get_event(c, ev + 1);
+    }
+    if (time_filter && acct) { HIPCHK(c, hipEventRecord(get_event(c, ev), s)); }
+    st = launch_filter(c, s, r, hi, nq, QT, cap);
+    c->launch_e0 = nullptr; c->launch_e1 = nullptr;
+    if (st) return st;
+    if (time_filter && acct) { HIPCHK(c, hipEventRecord(get_event(c, ev + 1), s)); }
+    if (time_filter) { c->ev_filter.emplace_back(ev, ev + 1); ev += 2; }
+    if (acct) c->klaunch.push_back(kl);
+    if ((st = launch_select(c, s, nq, cap, k_eff, slack, 0, nullptr, nullptr, 0))) return st;
+    c->stats.chunks++;
+    c->stats.rows_scanned += static_cast<uint64_t>(hi - r) * QT;
+    r = hi;
+    size = static_cast<uint64_t>(r) * (growth - 1);   // rows seen so far x (growth-1)
+  }
+  if (n_al < n) {   // ragged tail of an adopted corpus: exact scores, pruned by the current thresholds
+    // (fewer than one tile of rows per workgroup: the wavefront lists' 64 entries keep every row that clears the threshold)
+    if ((st = launch_scan_exact(c, s, n_al, n, dev_q, nq, std::min(k_eff, WAVE_KMAX), static_cast<const float*>(c->thr.p), cap, 0))) return st;
+    c->stats.rows_scanned += static_cast<uint64_t>(n - n_al) * QT;
+  }
+  // the final select rides in the rescore launch (one workgroup per query in both); its last workgroup folds the self-check words
+  FinalSelect fs{};
+  if (c->opt_fuse)
+    fs = FinalSelect{final_mode, k_eff, k, c->row_base, reinterpret_cast<unsigned long long*>(dev_out_ids), dev_out_scores, static_cast<float*>(c->thr.p),
+                     static_cast<uint32_t*>(c->overflow.p), static_cast<uint32_t*>(c->misc.p) + 6,
+                     prep_inits ? static_cast<uint32_t*>(c->tickets.p) + (FUSE_TICKETS - 1) : nullptr, prep_inits ? status_out : nullptr};
+  if (fs.mode == 1 && fs.ticket == nullptr) fs.mode = 0;          // (the sticky fold needs the ticket: separate select launch)
+  bool fused = false;
+  if ((st = launch_rescore(c, s, dev_q, nq, cap, fs, &fused))) return st;
+  if (fused) { c->status_by_kernel = fs.status_out != nullptr; return NVDB_OK; }
+  return launch_select(c, s, nq, cap, k_eff, nullptr, final_mode, dev_out_ids, dev_out_scores, k);
+}
+
+}  // namespace nvdbhip
+
+extern "C" {
+
+static nvdb_status search_args(nvdb_hip_ctx* c, const void* q, uint32_t nq, uint32_t k, const void* oi, const void* os) {
+  if (!c) return NVDB_ERR_INVALID;
+  if (!c->rows || c->n == 0) return fail(c, NVDB_ERR_NO_CORPUS, "Empty base");
+  if (nq > 0 && k > 0 && (!q || !oi || !os)) return fail(c, NVDB_ERR_INVALID, q ? "null output" : "Null query");
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_search_batch_dev(nvdb_hip_ctx* c, const float* dev_q, uint32_t nq, uint32_t k, uint64_t* dev_out_ids,
+                                      float* dev_out_scores, void* hip_stream) {
+  nvdb_status st = search_args(c, dev_q, nq, k, dev_out_ids, dev_out_scores);
+  if (st) return st;
+  if (nq == 0 || k == 0) return NVDB_OK;
+  if (nq > 2048) return fail(c, NVDB_ERR_UNSUPPORTED, "search_batch_dev: at most 2048 queries per call");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+  return search_core(c, s, dev_q, nq, k, dev_out_ids, dev_out_scores, 0, false);
+}
+
+// own_only: the host API's view of ITS OWN last search (misc[0], [1], per-query flags); the sticky words that device-API
+// searches left for the caller's next nvdb_hip_search_check are neither read into the verdict nor cleared
+static nvdb_status search_check_impl(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats, bool own_only) {
+  if (!c) return NVDB_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  // caller has synchronised its stream; read the self-check words
+  std::vector<uint32_t> ovf(c->last_nq);
+  uint32_t misc[16] = {0};
+  if (c->last_nq) HIPCHK(c, hipMemcpy(ovf.data(), c->overflow.p, c->last_nq * 4, hipMemcpyDeviceToHost));
+  if (c->misc.p) {
+    HIPCHK(c, hipMemcpy(misc, c->misc.p, 64, hipMemcpyDeviceToHost));
+    if (own_only) misc[12] = misc[13] = misc[14] = 0;
+    const uint32_t zero[3] = {0, 0, 0};             // sticky words (select_kernel): what ANY search since the last check found
+    if (misc[12] | misc[13] | misc[14]) HIPCHK(c, hipMemcpy(static_cast<uint32_t*>(c->misc.p) + 12, zero, 12, hipMemcpyHostToDevice));
+  }
+  c->stats.sticky_overflow = (misc[12] | misc[14]) ? 1u : 0u;
+  c->stats.sticky_violations = misc[13];
+  c->stats.i8_stage1_tiles = misc[4]; c->stats.i8_stage2_blocks = misc[5];
+  uint32_t nov = 0;
+  for (uint32_t v : ovf) nov += v ? 1u : 0u;
+  if (std::getenv("NVDB_DEBUG_OVERFLOW") && (nov || misc[1])) {
+    std::vector<uint32_t> cn(c->last_nq);
+    (void)hipMemcpy(cn.data(), c->cnt.p, c->last_nq * 4, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "[nvdb debug] log_overflow=%u list flags:", misc[1]);
+    for (uint32_t q = 0; q < c->last_nq; ++q) if (ovf[q]) std::fprintf(stderr, " q%u(cnt=%u)", q, cn[q]);
+    std::fprintf(stderr, "\n");
+  }
+  if (misc[1]) nov = c->last_nq;                 // a wave's survivor log overflowed: which queries lost entries is unknown
+  c->stats.overflow_queries = nov;
+  c->stats.bound_violations = misc[0];
+  // candidates that reached the rescore = the list lengths left by the last thresholding select (the final select
+  // does not touch them); summed here rather than by 1024 same-address atomics in the rescore kernel
+  unsigned long long tot = 0;
+  if (c->last_filter && c->last_nq) {
+    std::vector<uint32_t> cn(c->last_nq);
+    HIPCHK(c, hipMemcpy(cn.data(), c->cnt.p, c->last_nq * 4, hipMemcpyDeviceToHost));
+    for (uint32_t v : cn) tot += std::min(v, c->last_cap);
+  }
+  c->stats.candidates = tot;
+  float fms = 0.f;
+  for (auto& pr : c->ev_filter) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_pool[pr.first], c->ev_pool[pr.second]) == hipSuccess) fms += ms; }
+  c->stats.filter_kernel_ms = fms;
+  if (stats) *stats = c->stats;
+  if (misc[0]) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated (bound_violations > 0)");
+  if (nov) return fail(c, NVDB_ERR_INTERNAL, "candidate list overflow: re-run these queries with option path=1");
+  if (misc[13]) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated in an earlier search since the last check");
+  if (misc[12] | misc[14]) return fail(c, NVDB_ERR_INTERNAL, "candidate list overflow in an earlier search since the last check");
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_search_check(nvdb_hip_ctx* c, nvdb_hip_scan_stats* stats) { return search_check_impl(c, stats, false); }
+
+nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_t nq, uint32_t k, uint64_t* out_ids,
+                                  float* out_scores, uint32_t* out_k_eff, nvdb_hip_timing* timing) {
+  nvdb_status st = search_args(c, queries, nq, k, out_ids, out_scores);
+  if (st) return st;
+  if (timing) std::memset(timing, 0, sizeof(*timing));
+  if (out_k_eff) *out_k_eff = static_cast<uint32_t>(std::min<uint64_t>(k, c->n));
+  if (nq == 0 || k == 0) return NVDB_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t qbytes = static_cast<size_t>(nq) * c->dim * 4;
+  {
+    const size_t before = c->q32.p ? c->q32.bytes : 0;
+    if ((st = ensure(c, c->q32, qbytes + 8 * static_cast<size_t>(c->dim) * 4))) return st;
+    if (c->q32.bytes != before) { HIPCHK(c, hipMemsetAsync(c->q32.p, 0, c->q32.bytes, s)); c->q32_dirty = 0; }   // a new buffer starts all zero (zero_pad below)
+  }
+  if (nq <= 1024) { if ((st = ensure_hostblock(c, static_cast<size_t>(nq) * k * 12))) return st; }
+  else {
+    if ((st = ensure(c, c->out_ids, static_cast<size_t>(nq) * k * 8))) return st;
+    if ((st = ensure(c, c->out_scores, static_cast<size_t>(nq) * k * 4))) return st;
+  }
+  hipEvent_t e0 = get_event(c, 60), e1 = get_event(c, 61), e2 = get_event(c, 62), e3 = get_event(c, 63);
+  c->stats_lazy = false;
+  const size_t pad_bytes = 8 * static_cast<size_t>(c->dim) * 4;
+  // The 8 query rows after the batch must read as zeros (the exact kernel loads query groups of 8).  The buffer is zero beyond
+  // q32_dirty (zeroed when allocated, only ever written through [0, qbytes) of some call): a memset is enqueued only when an
+  // earlier, larger batch left queries where this call's padding lies.
+  auto zero_pad = [&]() -> nvdb_status {
+    if (c->q32_dirty > qbytes) HIPCHK(c, hipMemsetAsync(static_cast<char*>(c->q32.p) + qbytes, 0, std::min(pad_bytes, c->q32_dirty - qbytes), s));
+    c->q32_dirty = std::max(c->q32_dirty, qbytes);
+    return NVDB_OK;
+  };
+  if (nq <= 1024) {
+    // One sub-batch: everything the host needs comes back in ONE synchronisation through pinned staging -- the
+    // self-check words (32 B), ids and scores -- instead of five small pageable copies of ~20 us each (a third of
+    // a single-query search at N = 1M).  Small query blocks go up through the same staging buffer.
+    // Small calls (zero_copy, round 4) enqueue NO copy at all: the prep launch reads the queries from the pinned block over
+    // PCIe (and leaves the device copy the later kernels read), the final launch writes ids, scores and -- its last workgroup --
+    // the status words into the pinned block; the host only synchronises.  Two blit launches + their gaps less per search.
+    const size_t ob_ids = static_cast<size_t>(nq) * k * 8, ob_sc = static_cast<size_t>(nq) * k * 4;
+    const size_t q_stage = qbytes <= 64 * 1024 ? qbytes : 0;
+    const bool stage_out = ob_ids + ob_sc <= (static_cast<size_t>(16) << 20);     // very large k: results go straight to the caller's buffers
+    const bool zc_in = c->opt_zero_copy && q_stage != 0;
+    const bool zc_out = c->opt_zero_copy && stage_out && ob_ids + ob_sc <= 64 * 1024;
+    const size_t need = 64 + (stage_out ? ob_ids + ob_sc : 0) + q_stage;
+    if (c->pinned_bytes < need) {
+      if (c->pinned) (void)hipHostFree(c->pinned);
+      c->pinned = nullptr; c->pinned_bytes = 0; c->pinned_dev = nullptr;
+      HIPCHK(c, hipHostMalloc(&c->pinned, need + need / 2, hipHostMallocDefault));
+      c->pinned_bytes = need + need / 2;
+      HIPCHK(c, hipHostGetDevicePointer(&c->pinned_dev, c->pinned, 0));
+    }
+    char* pin = static_cast<char*>(c->pinned);
+    char* pin_d = static_cast<char*>(c->pinned_dev);                              // the same block as the kernels address it
+    uint32_t* pin_status = reinterpret_cast<uint32_t*>(pin);
+    const size_t off_ids = 64, off_sc = off_ids + (stage_out ? ob_ids : 0), off_q = off_sc + (stage_out ? ob_sc : 0);
+    char* pin_ids = pin + off_ids; char* pin_sc = pin + off_sc; char* pin_q = pin + off_q;
+    if (timing) HIPCHK(c, hipEventRecord(e0, s));
+    if ((st = zero_pad())) return st;
+    const float* host_q = nullptr;                                                 // non-null: search_core brings the queries down itself
+    if (q_stage) {
+      std::memcpy(pin_q, queries, qbytes);
+      if (zc_in) host_q = reinterpret_cast<const float*>(pin_d + off_q);
+      else HIPCHK(c, hipMemcpyAsync(c->q32.p, pin_q, qbytes, hipMemcpyHostToDevice, s));
+    } else HIPCHK(c, hipMemcpyAsync(c->q32.p, queries, qbytes, hipMemcpyHostToDevice, s));
+    if (timing) HIPCHK(c, hipEventRecord(e1, s));
+    const float* dq = static_cast<const float*>(c->q32.p);
+    uint64_t* oi = zc_out ? reinterpret_cast<uint64_t*>(pin_d + off_ids) : reinterpret_cast<uint64_t*>(static_cast<char*>(c->hostblock.p) + 64);
+    float* os = zc_out ? reinterpret_cast<float*>(pin_d + off_sc) : reinterpret_cast<float*>(static_cast<char*>(c->hostblock.p) + 64 + ob_ids);
+    uint32_t* st_out = zc_out ? reinterpret_cast<uint32_t*>(pin_d) : nullptr;
+    if ((st = search_core(c, s, dq, nq, k, oi, os, 0, timing != nullptr && c->opt_time_launches, 0, false, host_q, st_out))) return st;
+    if (timing) HIPCHK(c, hipEventRecord(e2, s));
+    auto fetch = [&]() -> nvdb_status {
+      if (zc_out) {
+        // ids and scores were written into the pinned block by the final kernel; the status words too when that kernel was the
+        // fused rescore + select (else: 32 bytes copied here)
+        if (!c->status_by_kernel) HIPCHK(c, hipMemcpyAsync(pin_status, c->misc.p, 32, hipMemcpyDeviceToHost, s));
+      } else if (stage_out) {
+        // status words, ids and scores are adjacent on the device (ensure_hostblock) and in the staging buffer: ONE copy
+        HIPCHK(c, hipMemcpyAsync(pin, c->hostblock.p, 64 + ob_ids + ob_sc, hipMemcpyDeviceToHost, s));
+      } else {
+        HIPCHK(c, hipMemcpyAsync(pin_status, c->misc.p, 32, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(out_ids, oi, ob_ids, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(out_scores, os, ob_sc, hipMemcpyDeviceToHost, s));
+      }
+      if (timing) HIPCHK(c, hipEventRecord(e3, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      return NVDB_OK;
+    };
+    if ((st = fetch())) return st;
+    nvdb_hip_scan_stats part = c->stats;
+    if (pin_status[0] | pin_status[1] | pin_status[6]) {
+      // self-check tripped (rare): exact counts for the statistics, then redo the batch -- first on the filter path with
+      // the longest candidate lists the select kernel can sort (near-duplicate-heavy corpora: thousands of rows inside
+      // the filter's error band of the k-th score; re-scoring them is cheap, only the list was too short), and if that
+      // is still not enough, or the bound itself was violated, on the always-correct exact path
+      // (the queries are in the device buffer by now: the retries read them there)
+      nvdb_status chk = search_check_impl(c, &part, true);
+      if (chk == NVDB_ERR_HIP) return chk;
+      bool done = false;
+      if (part.path == 2 && !pin_status[0] && c->last_cap < SELECT_MAX_CAP) {
+        if ((st = search_core(c, s, dq, nq, k, oi, os, 2, false, SELECT_MAX_CAP, false, nullptr, st_out))) return st;
+        if ((st = fetch())) return st;
+        done = !(pin_status[0] | pin_status[1] | pin_status[6]);
+        if (done) c->cap_hint = SELECT_MAX_CAP;
+      }
+      if (!done) {
+        if ((st = search_core(c, s, dq, nq, k, oi, os, 1, false, 0, false, nullptr, st_out))) return st;
+        if ((st = fetch())) return st;
+      }
+      c->stats = part;
+    } else {
+      part.i8_stage1_tiles = pin_status[4]; part.i8_stage2_blocks = pin_status[5];
+      float fms = 0.f;
+      for (auto& pr : c->ev_filter) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_pool[pr.first], c->ev_pool[pr.second]) == hipSuccess) fms += ms; }
+      part.filter_kernel_ms = fms;
+      c->stats = part;
+      c->stats_lazy = c->last_filter;                 // candidates: read back on demand
+    }
+    if (stage_out) {
+      std::memcpy(out_ids, pin_ids, ob_ids);
+      std::memcpy(out_scores, pin_sc, ob_sc);
+    }
+    if (timing) {
+      (void)hipEventElapsedTime(&timing->h2d_ms, e0, e1);
+      (void)hipEventElapsedTime(&timing->kernel_ms, e1, e2);
+      (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
+      timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
+      timing->threads = 256; timing->nwarps = 4; timing->K = k;
+      timing->shmem_bytes = part.path != 2 ? 0 : c->dtype == NVDB_DTYPE_I8 ? static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * c->fdim + 4096) : static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * 2;
+    }
+    if (part.bound_violations) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated; results were recomputed on the exact path");
+    return NVDB_OK;
+  }
+  if ((st = zero_pad())) return st;
+  HIPCHK(c, hipEventRecord(e0, s));
+  HIPCHK(c, hipMemcpyAsync(c->q32.p, queries, qbytes, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipEventRecord(e1, s));
+  nvdb_hip_scan_stats total{};
+  float filter_ms = 0.f;
+  for (uint32_t q0 = 0; q0 < nq; q0 += 1024) {
+    const uint32_t b = std::min<uint32_t>(1024, nq - q0);
+    const float* dq = static_cast<const float*>(c->q32.p) + static_cast<size_t>(q0) * c->dim;
+    uint64_t* oi = static_cast<uint64_t*>(c->out_ids.p) + static_cast<size_t>(q0) * k;
+    float* os = static_cast<float*>(c->out_scores.p) + static_cast<size_t>(q0) * k;
+    if ((st = search_core(c, s, dq, b, k, oi, os, 0, timing != nullptr && c->opt_time_launches, 0, false))) return st;
+    HIPCHK(c, hipStreamSynchronize(s));
+    nvdb_hip_scan_stats part{};
+    nvdb_status chk = search_check_impl(c, &part, true);
+    if (chk == NVDB_ERR_HIP) return chk;
+    if (chk == NVDB_ERR_INTERNAL) {
+      // self-check tripped: longest lists first, then the always-correct exact path (see the small-call path above)
+      bool done = false;
+      if (part.path == 2 && !part.bound_violations && c->last_cap < SELECT_MAX_CAP) {
+        if ((st = search_core(c, s, dq, b, k, oi, os, 2, false, SELECT_MAX_CAP, false))) return st;
+        HIPCHK(c, hipStreamSynchronize(s));
+        nvdb_hip_scan_stats again{};
+        const nvdb_status chk2 = search_check_impl(c, &again, true);
+        if (chk2 == NVDB_ERR_HIP) return chk2;
+        done = (chk2 == NVDB_OK);
+        if (done) c->cap_hint = SELECT_MAX_CAP;
+      }
+      if (!done) {
+        if ((st = search_core(c, s, dq, b, k, oi, os, 1, false, 0, false))) return st;
+        HIPCHK(c, hipStreamSynchronize(s));
+      }
+    }
+    total.path = std::max(total.path, part.path);
+    total.chunks += part.chunks; total.rows_scanned += part.rows_scanned; total.candidates += part.candidates;
+    total.overflow_queries += part.overflow_queries; total.bound_violations += part.bound_violations;
+    total.i8_stage1_tiles += part.i8_stage1_tiles; total.i8_stage2_blocks += part.i8_stage2_blocks;
+    filter_ms += part.filter_kernel_ms;
+  }
+  HIPCHK(c, hipEventRecord(e2, s));
+  HIPCHK(c, hipMemcpyAsync(out_ids, c->out_ids.p, static_cast<size_t>(nq) * k * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(out_scores, c->out_scores.p, static_cast<size_t>(nq) * k * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipEventRecord(e3, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  total.filter_kernel_ms = filter_ms;
+  c->stats = total;
+  if (timing) {
+    (void)hipEventElapsedTime(&timing->h2d_ms, e0, e1);
+    (void)hipEventElapsedTime(&timing->kernel_ms, e1, e2);
+    (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
+    timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
+    timing->threads = 256; timing->nwarps = 4; timing->K = k;
+    timing->shmem_bytes = total.path != 2 ? 0 : c->dtype == NVDB_DTYPE_I8 ? static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * c->fdim + 4096) : static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * 2;
+  }
+  if (total.bound_violations) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated; results were recomputed on the exact path");
+  return NVDB_OK;
+}
+
+nvdb_status nvdb_hip_collect_kernel_times(nvdb_hip_ctx* c, uint32_t* launches, double* total_ms, double* total_flops,
+                                          double* total_bytes) {
+  if (!c) return NVDB_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  double ms = 0, fl = 0, by = 0;
+  uint32_t cnt = 0;
+  for (auto& k : c->klaunch) {
+    float t = 0.f;
+    HIPCHK(c, hipEventSynchronize(k.e1));
+    HIPCHK(c, hipEventElapsedTime(&t, k.e0, k.e1));
+    ms += t; fl += k.flops; by += k.bytes; ++cnt;
+    c->kl_pool.push_back(k.e0); c->kl_pool.push_back(k.e1);
+  }
+  c->klaunch.clear();
+  if (launches) *launches = cnt;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (total_bytes) *total_bytes = by;
+  return NVDB_OK;
+}
+
+}  // extern "C"

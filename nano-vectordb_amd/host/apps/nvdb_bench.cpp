@@ -93,10 +93,13 @@ int main(int argc, char** argv) {
   const uint64_t Q = query.count();
   std::cout << "Base count=" << base.count() << " dim=" << base.dim() << " | Query count=" << Q << " | k=" << k << " | warmup=" << warmup << "\n";
   for (int i = 0; i < warmup; ++i) (void)run_query(query.vector_ptr(0));
-  if (gpu) {
-    // GPU mode only: map the query file's pages before the timed loop.  Every batch reads a fresh 3 MB of the mmap; the
-    // ~800 first-touch page-cache faults per batch (0.3-0.4 ms) are file plumbing of the harness, a third of a percent of a
-    // CPU batch but 3 % of an 11 ms GPU batch.  The CPU modes are left exactly as the reference times them.
+  // NVDB_BENCH_PREFAULT=1 (any mode; off by default = exactly the reference's timing rules, apps/nvdb_bench.cpp:317-359): map the
+  // query file's pages before the timed loop.  Every batch reads a fresh 3 MB of the mmap; its ~800 first-touch page-cache faults
+  // (0.3-0.4 ms) are file plumbing of the harness, a third of a percent of a CPU batch but 3 % of an 11 ms GPU batch.  The last
+  // line of the GPU mode says which rule the run used (gpu_prefault=0|1); bench.py reports both.
+  const char* pf = std::getenv("NVDB_BENCH_PREFAULT");
+  const bool prefault = pf && pf[0] == '1';
+  if (prefault) {
     volatile float touch = 0.f;
     const size_t step = 4096 / sizeof(float);
     for (uint64_t qi = 0; qi < Q; ++qi) { const float* qp = query.vector_ptr_f32(qi); for (size_t j = 0; j < base.dim(); j += step) touch = touch + qp[j]; }
@@ -202,7 +205,7 @@ int main(int argc, char** argv) {
               << " gpu_algorithmic_GBps=" << (gpu_kernel_ms > 0 ? passes * bytes_per_query * 1e-6 / gpu_kernel_ms : 0.0)
               << " gpu_upload_s=" << gpu_upload_s << " gpu_upload_GBps=" << (gpu_upload_s > 0 ? bytes_per_query * 1e-9 / gpu_upload_s : 0.0)
               << " gpu_exchange=" << (hip_sharded ? (hip_sharded->exchange_is_rccl() ? "rccl" : "peer-copy") : "none")
-              << " gpu_host_merge_fallbacks=" << (hip_sharded ? hip_sharded->host_merge_fallbacks() : 0u) << "\n";
+              << " gpu_host_merge_fallbacks=" << (hip_sharded ? hip_sharded->host_merge_fallbacks() : 0u) << " gpu_prefault=" << (prefault ? 1 : 0) << "\n";
   }
   return 0;
 }

@@ -1306,24 +1306,44 @@ def test_exact_scores_on_the_fp32_matrix_cores(oracle, tag, d, nq):
     c = nvdb_amd.HipContext(0)
     c.upload_corpus(base, dt, scales)
     c.set_option("path", 1)
-    res = {}
-    for mf in (1, 2, 0):                                                 # 1: LDS-staged tiles for full groups of 64 queries, 2: register-direct loads only, 0: VALU kernels
-        c.set_option("exact_mfma", 1 if mf else 0)
-        c.set_option("exact_lds", 2 if mf == 1 else 0)
-        res[mf] = c.search_batch(queries, k)
-        assert c.stats()["path"] == 1
-    for mf in (1, 2):
-        assert np.array_equal(res[mf][0], res[0][0]) and np.array_equal(res[mf][1].view(np.uint32), res[0][1].view(np.uint32)), mf
+    # kernel builds: fp32 LDS image (fp16 / int8 rows, full groups of 64 queries; the default), raw tiles staged through LDS,
+    # register-direct loads only, and the VALU kernels
+    MODES = {"img": dict(exact_mfma=1, exact_img=1, exact_lds=1), "lds": dict(exact_mfma=1, exact_img=0, exact_lds=2),
+             "reg": dict(exact_mfma=1, exact_img=0, exact_lds=0), "valu": dict(exact_mfma=0, exact_img=0, exact_lds=0)}
+
+    def run(qs, kk):
+        out = {}
+        for name, opts in MODES.items():
+            for key, val in opts.items():
+                c.set_option(key, val)
+            out[name] = c.search_batch(qs, kk)
+        return out
+
+    res = run(queries, k)
+    assert c.stats()["path"] == 1
+    for name in ("img", "lds", "reg"):
+        assert np.array_equal(res[name][0], res["valu"][0]) and np.array_equal(res[name][1].view(np.uint32), res["valu"][1].view(np.uint32)), name
     sub = np.r_[0:8, nq - 1]
-    _check_against_oracle(oracle, base, dt, scales, queries[sub], res[1][0][sub], res[1][1][sub], k, f"exact-mfma/{tag}/d{d}")
+    _check_against_oracle(oracle, base, dt, scales, queries[sub], res["img"][0][sub], res["img"][1][sub], k, f"exact-mfma/{tag}/d{d}")
+    # SUBNORMAL scores as the top-k (the tiny rows above never reach a top-10): every query scaled by 1e-37, so every query element (~4e-39),
+    # product (~1e-40) and nearly every sum (~4e-39) is an fp32 subnormal -- a matrix core that flushed subnormal inputs or outputs
+    # would return zeros here; the fma chain and the oracle do not
+    tiny_q = (queries * np.float32(1e-37)).astype(np.float32)
+    tiny_q[2] = queries[0] * np.float32(1e-37)                           # (query 2 was scaled up above)
+    rt = run(tiny_q, k)
+    for name in ("img", "lds", "reg"):
+        assert np.array_equal(rt[name][0], rt["valu"][0]) and np.array_equal(rt[name][1].view(np.uint32), rt["valu"][1].view(np.uint32)), ("subnormal", name)
+    _check_against_oracle(oracle, base, dt, scales, tiny_q[sub], rt["img"][0][sub], rt["img"][1][sub], k, f"exact-mfma subnormal/{tag}/d{d}")
     # the any-k path's score matrix comes from the same tiles (k = 100 on 20K rows is off the filter path)
-    for mf in (1, 2, 0):
-        c.set_option("exact_mfma", 1 if mf else 0)
-        c.set_option("exact_lds", 2 if mf == 1 else 0)
-        res[mf] = c.search_batch(queries, 100)
-        assert c.stats()["path"] == 3
-    for mf in (1, 2):
-        assert np.array_equal(res[mf][0], res[0][0]) and np.array_equal(res[mf][1].view(np.uint32), res[0][1].view(np.uint32)), mf
+    res = run(queries, 100)
+    assert c.stats()["path"] == 3
+    for name in ("img", "lds", "reg"):
+        assert np.array_equal(res[name][0], res["valu"][0]) and np.array_equal(res[name][1].view(np.uint32), res["valu"][1].view(np.uint32)), name
+    rt = run(tiny_q, n)                                                  # k = n: EVERY row's score, in order -- most of them subnormal
+    a0 = np.abs(rt["valu"][1][0])
+    assert np.count_nonzero((a0 > 0) & (a0 < np.float32(1.17e-38))) > n // 2, "the tiny queries must produce subnormal, non-zero scores"
+    for name in ("img", "lds", "reg"):
+        assert np.array_equal(rt[name][0], rt["valu"][0]) and np.array_equal(rt[name][1].view(np.uint32), rt["valu"][1].view(np.uint32)), ("subnormal any-k", name)
     c.close()
 
 
@@ -1343,12 +1363,14 @@ def test_exact_mfma_lds_kernel_on_an_adopted_unpadded_corpus(oracle):
         c = nvdb_amd.HipContext(0)
         c.adopt_corpus(t_rows.data_ptr(), n, d, dt, t_scales.data_ptr() if t_scales is not None else None)
         c.set_option("path", 1)
-        c.set_option("exact_lds", 2)                               # the LDS-staged build for every dtype (default: fp32 rows only)
+        gi, gs = c.search_batch(queries, k)                        # defaults: the fp32-image build for fp16 / int8 rows, raw LDS stages for fp32 rows
+        c.set_option("exact_lds", 2)                               # the raw LDS-staged build for every dtype
         ids, sc = c.search_batch(queries, k)
         c.set_option("exact_mfma", 0)
         ei, es = c.search_batch(queries, k)
         c.close()
         assert np.array_equal(ids, ei) and np.array_equal(sc.view(np.uint32), es.view(np.uint32)), tag
+        assert np.array_equal(gi, ei) and np.array_equal(gs.view(np.uint32), es.view(np.uint32)), (tag, "default build")
         assert ids[7, 0] == n - 2
         _check_against_oracle(oracle, base, {"f16": po.DT_F16, "i8": po.DT_I8, "f32": po.DT_F32}[tag], scales, queries[5:9], ids[5:9], sc[5:9], k, f"exact-lds adopt/{tag}")
 

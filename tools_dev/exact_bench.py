@@ -9,7 +9,7 @@ import numpy as np, torch, nvdb_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 K = 10
-MODES = ["valu", "mfma+lds", "mfma register-direct"]
+MODES = ["valu", "mfma raw LDS stages", "mfma register-direct", "mfma fp32 LDS image"]
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 strm = torch.cuda.current_stream().cuda_stream
@@ -22,8 +22,9 @@ for tag, dt in (("f16", nvdb_amd.DT_F16), ("i8", nvdb_amd.DT_I8), ("f32", nvdb_a
         oi = torch.empty((nq, K), dtype=torch.int64, device=dev); os_ = torch.empty((nq, K), dtype=torch.float32, device=dev)
         ref = None
         for rnd in range(2):
-            for mf in (1, 2, 0):
-                ctx.set_option("exact_mfma", 1 if mf else 0); ctx.set_option("exact_lds", 2 if mf == 1 else 0)
+            for mf in (3, 1, 2, 0):
+                if mf == 3 and tag == "f32": continue
+                ctx.set_option("exact_mfma", 1 if mf else 0); ctx.set_option("exact_lds", 2 if mf == 1 else 0); ctx.set_option("exact_img", 1 if mf == 3 else 0)
                 ctx.search_batch_dev(q.data_ptr(), nq, K, oi.data_ptr(), os_.data_ptr(), strm)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 reps = 3

@@ -4,10 +4,12 @@ usage: trace_timeline.py <dir>"""
 import csv, glob, os, sys
 f = sorted(glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# last search = from the last init_search_kernel on
-idx = max(i for i, r in enumerate(rows) if "init_search_kernel" in r["Kernel_Name"])
-# take the previous complete one (the last may be bench.py's self-check)
-starts = [i for i, r in enumerate(rows) if "init_search_kernel" in r["Kernel_Name"]]
+# a search starts with init_search_kernel, or -- when the prep launch does the resets itself (option fuse) -- with the prep kernel
+def is_start(i):
+    nm = rows[i]["Kernel_Name"]
+    if "init_search_kernel" in nm: return True
+    return ("prep_q16" in nm or "prep_q8" in nm) and not (i > 0 and "init_search_kernel" in rows[i - 1]["Kernel_Name"])
+starts = [i for i in range(len(rows)) if is_start(i)]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 a, b = starts[-n], starts[-n + 1]
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = t0
