@@ -1,5 +1,5 @@
 /*
- * nvdb_hip_dev.h -- developer entry points of libnvdb_hip_dev.so (csrc/nvdb_hip.cpp compiled with -DNVDB_HIP_DEV).
+ * nvdb_hip_dev.h -- developer entry points of libnvdb_hip_dev.so (csrc/nvdb_debug.cpp; the library built with -DNVDB_HIP_DEV).
  *
  * NOT part of the drop-in surface: the product library libnvdb_hip.so exports none of these and contains none of the
  * timing-only kernel builds behind them (they return wrong results by design).  The dev library is a superset of the

@@ -172,6 +172,21 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   uint32_t boot_tiles = std::max<uint32_t>(64u, 8u * k_eff);
   if (c->opt_boot_tiles > 0) boot_tiles = std::max<uint32_t>(boot_tiles, std::min<uint32_t>(static_cast<uint32_t>(c->opt_boot_tiles), cap));
   else if (i8_log && !k_wide) boot_tiles = std::max<uint32_t>(boot_tiles, std::min<uint32_t>(1024u, cap));
+  else if (!k_wide) {
+    // A bootstrap of up to 256 tiles that saves a whole chunk (a filter launch + its select, ~12 us) pays for itself; a larger
+    // bootstrap that saves none does not (profiles/r04_boot_tiles_sweep.txt: 500K rows 3 -> 2 chunks -9 us, 2.9M rows 4 -> 3 chunks
+    // -14..-28 us; 1M / 10M rows, where 256 tiles save nothing: +0.5..2 %).  So: the smallest bootstrap <= 256 tiles with which the
+    // chunks (each `growth` x the rows before it) reach the corpus one launch earlier.
+    uint64_t reach = static_cast<uint64_t>(FILTER_ROWS) * boot_tiles, per = 1;
+    uint32_t J = 0;
+    while (reach < n) { reach *= growth; per *= growth; ++J; }
+    if (J >= 2) {
+      per /= growth;                                                             // growth^(J-1)
+      uint64_t need = (static_cast<uint64_t>(n) + per * FILTER_ROWS - 1) / (per * FILTER_ROWS);
+      need = (need + 3) & ~3ull;                                                 // chunk boundaries stay multiples of the 64-row tiles whatever the growth
+      if (need > boot_tiles && need <= 256 && need <= cap) boot_tiles = static_cast<uint32_t>(need);
+    }
+  }
   const uint32_t boot_rows = FILTER_ROWS * boot_tiles;
   const bool mfma_boot = c->opt_mfma_boot && n >= boot_rows && boot_rows / FILTER_ROWS >= k_eff &&
                          boot_rows / FILTER_ROWS <= cap &&
