@@ -81,7 +81,7 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
 // T at a time), enqueue its H2D DMA, go on with the next chunk while the DMA runs; a buffer is reused when its event has fired.
 // NVDB_UPLOAD_THREADS overrides T (1 = the plain chunked hipMemcpy).
 nvdb_status upload_rows(nvdb_hip_ctx* c, void* dst, const void* src, size_t bytes) {
-  unsigned T = std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 2));
+  unsigned T = std::min(6u, std::max(2u, std::thread::hardware_concurrency() / 2));   // 6: the plateau on the bench host (profiles/r04_upload_bench.txt)
   if (const char* e = std::getenv("NVDB_UPLOAD_THREADS")) T = static_cast<unsigned>(std::max(1, std::atoi(e)));
   constexpr size_t CH = size_t(8) << 20;
   const size_t nch = (bytes + CH - 1) / CH;
@@ -102,8 +102,10 @@ nvdb_status upload_rows(nvdb_hip_ctx* c, void* dst, const void* src, size_t byte
     bool used[2] = {false, false};
     auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && errs[t].empty()) errs[t] = std::string(what) + ": " + hipGetErrorString(e); return e == hipSuccess; };
     bool ok = chk(hipSetDevice(c->device), "hipSetDevice") && chk(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    const auto tp0 = std::chrono::steady_clock::now();
     for (int b = 0; b < 2 && ok; ++b)
       ok = chk(hipHostMalloc(&pin[b], CH, hipHostMallocDefault), "hipHostMalloc") && chk(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming), "hipEventCreate");
+    if (t == 0 && std::getenv("NVDB_UPLOAD_DEBUG")) std::fprintf(stderr, "[nvdb upload] thread 0: stream + 2 pinned buffers of %zu MB in %.1f ms\n", CH >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
     // chunks are handed out in order (an atomic counter): the threads walk the file front to back together
     for (int b = 0; ok; b ^= 1) {
       const size_t i = next.fetch_add(1);
@@ -212,17 +214,25 @@ nvdb_status nvdb_hip_upload_corpus(nvdb_hip_ctx* c, const void* rows, const floa
   free_corpus(c);
   const size_t bytes = static_cast<size_t>(n) * dim * bpe_of(dtype);
   const size_t pad = static_cast<size_t>(PAD_ROWS) * dim * bpe_of(dtype) + 4096;   // zero rows up to a whole tile (+ slack for vector loads)
+  const bool dbg = std::getenv("NVDB_UPLOAD_DEBUG") != nullptr;      // stderr: where an upload's time goes
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   HIPCHK(c, hipMalloc(&c->rows, bytes + pad));
   HIPCHK(c, hipMemset(static_cast<char*>(c->rows) + bytes, 0, pad));
   c->owned = true;
+  const double t_alloc = since();
   if ((st = upload_rows(c, c->rows, rows, bytes))) return st;
+  const double t_rows = since();
   if (dtype == NVDB_DTYPE_I8) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->scales), (n + PAD_ROWS) * sizeof(float)));
     HIPCHK(c, hipMemset(c->scales + n, 0, PAD_ROWS * sizeof(float)));
     HIPCHK(c, hipMemcpy(c->scales, scales, n * sizeof(float), hipMemcpyHostToDevice));
   }
   c->n = n; c->dim = dim; c->dtype = dtype; c->row_base = global_row_base;
-  return compute_max_norm(c);
+  st = compute_max_norm(c);
+  if (dbg) std::fprintf(stderr, "[nvdb upload] %.2f GB: device allocation %.1f ms, rows %.1f ms (%.1f GB/s), scales + row-norm pass (+ shadow copy) %.1f ms\n",
+                        bytes / 1e9, t_alloc, t_rows - t_alloc, bytes / 1e6 / (t_rows - t_alloc), since() - t_rows);
+  return st;
 }
 
 nvdb_status nvdb_hip_adopt_corpus(nvdb_hip_ctx* c, void* dev_rows, float* dev_scales, uint64_t n, uint32_t dim, uint32_t dtype,

@@ -179,3 +179,25 @@ def test_nvdb_cuda_refine_eval(files, dtkey, pinned):
     assert res["refine_k"] == "256" and res["Q"] == "8" and res["k"] == "10" and res["refine_backend"] == "cuda"
     assert float(res["recall_vs_cpu"]) == 1.0 and res["cuda_pinned"] == pinned
     assert "identical_rows=8/8" in out
+
+
+@pytest.mark.parametrize("sanitize", [False, True])
+def test_call_coalescer_without_a_gpu(tmp_path, sanitize):
+    """nvdb::detail::CallCoalescer (what lets FlatIndexHIP / FlatIndexHIPSharded serve overlapping callers with ONE GPU batch) driven by
+    tests/coalescer_check.cpp: a stand-in batch function that sleeps 200 us whatever the batch size; six threads x 50 calls
+    (single queries, some 3-query requests, some with another k).  Every caller gets its own rows, no two batches overlap, batches
+    are shared, an injected failure reaches its callers and only them.  Once plain (timing: six threads in well under 6x the solo
+    time) and once under ThreadSanitizer."""
+    exe = str(tmp_path / "coalescer_check")
+    flags = ["-O1", "-g", "-fsanitize=thread"] if sanitize else ["-O2"]
+    subprocess.run(["g++", "-std=c++17", *flags, "-I", os.path.join(ROOT, "nano-vectordb_amd", "host", "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "coalescer_check.cpp"), "-lpthread"], check=True)
+    r = subprocess.run([exe, "6", "50"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    kv = dict(p.split("=") for p in r.stdout.splitlines()[0].split())
+    assert int(kv["overlaps"]) == 0 and int(kv["wrong"]) == 0 and int(kv["max_batch"]) > 1
+    if not sanitize:
+        assert float(kv["par_ms"]) < 3.0 * float(kv["solo_ms"]), kv          # serialised it would be 6x
+    one = subprocess.run([exe, "1", "20"], capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr

@@ -17,10 +17,10 @@ for ci in range(cases):
     tag = rs.choice(["f16", "f16", "i8", "i8", "f32"])
     dim = int(rs.choice([8, 24, 64, 100, 128, 200, 256, 384, 500, 512, 640, 768, 768, 768, 896, 1000, 1024, 1152, 1280, 1408, 1536, 1600, 2048, 2560, 3072, 3100]))
     if tag == "i8" and dim > 768 and rs.rand() < 0.5: dim = 768
-    n = int(rs.choice([1, 7, 33, 500, 2047, 2048, 2049, 4096, 10000, 33333, 70001, 150000]))
+    n = int(rs.choice([1, 7, 33, 500, 2047, 2048, 2049, 4096, 10000, 33333, 70001, 150000, 400000]))      # (>= 131K rows: the adaptive bootstrap size comes into play)
     nq = int(rs.choice([1, 2, 31, 32, 33, 64, 65, 128, 129, 200, 256, 257, 700, 1024, 1100]))
     k = int(rs.choice([1, 3, 10, 10, 10, 33, 64, 64, 65, 100, 300, 1024, 1500]))      # > 64: wide k on the filter / the any-k path
-    if n * dim > 150000 * 768: n = 150000 * 768 // dim
+    if n * dim > 400000 * 384: n = 400000 * 384 // dim
     ctx.generate_corpus(1000 + ci, n, dim, DT[tag])
     q = nvdb_amd.synth_rows_f32(5000 + ci, 0, nq, dim)
     if rs.rand() < 0.3: q[0] *= np.float32(10.0 ** rs.uniform(-6, 6))
@@ -32,6 +32,10 @@ for ci in range(cases):
     if rs.rand() < 0.2: opts["xcd_balance"] = 0
     if rs.rand() < 0.2: opts["exact_mfma"] = 0
     if rs.rand() < 0.3: opts["exact_lds"] = int(rs.choice([0, 2]))
+    if rs.rand() < 0.25: opts["exact_img"] = 0
+    if rs.rand() < 0.25: opts["fuse"] = 0
+    if rs.rand() < 0.25: opts["zero_copy"] = 0
+    if rs.rand() < 0.2 and tag != "i8": opts["boot_tiles"] = int(rs.choice([96, 256, 300]))
     if tag == "i8":
         if rs.rand() < 0.25: opts["i8_defer"] = 1
         if rs.rand() < 0.2: opts["i8_lo_bits"] = int(rs.choice([3, 5, 6]))
@@ -47,7 +51,7 @@ for ci in range(cases):
             ok = ok and np.array_equal(ei[qi], oi[0]) and np.array_equal(es[qi].view(np.uint32), os_[0].view(np.uint32))
     except Exception as e:
         ok = False; st = {"error": str(e)}
-    for k_ in opts: ctx.set_option(k_, {"tile_permute": 1, "chunk_growth": 0, "mfma_boot": 1, "sibling_sync": 1, "xcd_balance": 1, "i8_defer": 0, "i8_lo_bits": 7, "boot_tiles": 0, "exact_mfma": 1, "exact_lds": 1}[k_])
+    for k_ in opts: ctx.set_option(k_, {"tile_permute": 1, "chunk_growth": 0, "mfma_boot": 1, "sibling_sync": 1, "xcd_balance": 1, "i8_defer": 0, "i8_lo_bits": 7, "boot_tiles": 0, "exact_mfma": 1, "exact_lds": 1, "exact_img": 1, "fuse": 1, "zero_copy": 1}[k_])
     ctx.set_option("path", 0)
     if not ok:
         fails += 1
