@@ -99,6 +99,9 @@ struct nvdb_hip_ctx {
   int64_t opt_time_launches = 0;                   // host API with a timing struct: 1 = also attach start / stop events to every filter launch (stats.filter_kernel_ms); costs ~0.1 ms per launch-rich pass
   int64_t opt_exact_lds = 1;                       // exact MFMA kernels: full groups of 64 queries stage their row tiles through LDS once per workgroup: 1 = for fp32 rows (101 vs 75 TFLOP/s; fp16 / int8 rows are faster register-direct: 86 vs 77), 2 = always, 0 = never
   int64_t opt_exact_img = 1;                       // exact MFMA kernels, fp16 / int8 rows, full groups of 64 queries: tile converted once per workgroup into an fp32 LDS image (exact_mfma_img_kernel); 0: register-direct / raw-staged builds
+  int64_t opt_exact_wgs = 1;                       // exact MFMA SCAN kernels: workgroups per CU in all (one is resident at a time).  1 = a single round: every workgroup pays the start-up of its
+                                                   // top-k lists (the first ~150 tiles of a stream take the insertion path) once, and the grid (wgs * CUs / query groups, rounded DOWN) never leaves
+                                                   // a partly filled last round -- 2, the value of round 3, cost 5-30 % (profiles/r04_exact_wgs_sweep.txt: 128 queries 67 -> 90 TFLOP/s)
   int64_t opt_exact_mfma = 1;                      // exact fp32-order scores on the fp32 matrix cores where the shape allows (kernels_exact_mfma.h); 0: VALU kernels only
   int64_t opt_rescore8 = 2;                        // rescore kernel: 0 lane per candidate, 1 eight lanes per candidate, 2 = 1 + rows staged through LDS
 

@@ -56,7 +56,7 @@ nvdb_status launch_scan_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_
     if ((c->opt_exact_lds == 2 || (c->opt_exact_lds == 1 && DT == DT_F32)) && nq >= 64 && c->dim == D) {                          \
       const uint32_t gy = nq / 64;                                                                                                 \
       const uint32_t pmax = (cap > reserve + k) ? (cap - reserve) / k : 1;                                                         \
-      uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);                                  \
+      uint32_t P = std::max<uint32_t>(1, (static_cast<uint32_t>(c->opt_exact_wgs) * static_cast<uint32_t>(c->num_cu)) / gy);                                  \
       P = std::max<uint32_t>(1, std::min(std::min(P, std::max<uint32_t>(1, tiles / 8)), pmax));                                    \
       const void* fn = reinterpret_cast<const void*>(exact_mfma_lds_kernel<DT, D, false>);                                         \
       if (!c->lds_attr_set.count(fn)) {                                                                                            \
@@ -75,7 +75,7 @@ nvdb_status launch_scan_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_
     if (c->opt_exact_img && c->opt_exact_lds != 2 && nq >= 64 && c->dim == D) {                                                    \
       const uint32_t gy = nq / 64;                                                                                                 \
       const uint32_t pmax = (cap > reserve + k) ? (cap - reserve) / k : 1;                                                         \
-      uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);                                  \
+      uint32_t P = std::max<uint32_t>(1, (static_cast<uint32_t>(c->opt_exact_wgs) * static_cast<uint32_t>(c->num_cu)) / gy);                                  \
       P = std::max<uint32_t>(1, std::min(std::min(P, std::max<uint32_t>(1, tiles / 8)), pmax));                                    \
       const void* fn = reinterpret_cast<const void*>(exact_mfma_img_kernel<DT, D, false>);                                         \
       if (!c->lds_attr_set.count(fn)) {                                                                                            \
@@ -100,7 +100,7 @@ nvdb_status launch_scan_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_
   const uint32_t last_blocks = (nr - (gy - 1) * 64 + 15) / 16;                    // 16-query blocks of the last (partial) group
   const uint32_t nslice_max = last_blocks >= 3 ? 1u : (last_blocks == 2 ? 2u : 4u);
   const uint32_t pmax = (cap > reserve + k * nslice_max) ? (cap - reserve) / (k * nslice_max) : 1;
-  uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);   // ~2 workgroups per CU in all (one resident at a time)
+  uint32_t P = std::max<uint32_t>(1, (static_cast<uint32_t>(c->opt_exact_wgs) * static_cast<uint32_t>(c->num_cu)) / gy);   // one workgroup per CU in all (see opt_exact_wgs)
   P = std::min(P, std::max<uint32_t>(1, tiles / 8));                                           // >= 8 tiles each
   P = std::max<uint32_t>(1, std::min(P, pmax));
   const dim3 grid(P, gy);
@@ -241,7 +241,7 @@ nvdb_status launch_scores_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, const float
   if constexpr (exact_lds_shape<DT, D>()) {                                                                                        \
     if ((c->opt_exact_lds == 2 || (c->opt_exact_lds == 1 && DT == DT_F32)) && nq >= 64 && c->dim == D) {                          \
       const uint32_t gy = nq / 64;                                                                                                 \
-      uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);                                  \
+      uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu)) / gy);                                  \
       P = std::max<uint32_t>(1, std::min(P, std::max<uint32_t>(1, tiles / 8)));                                                    \
       const void* fn = reinterpret_cast<const void*>(exact_mfma_lds_kernel<DT, D, true>);                                          \
       if (!c->lds_attr_set.count(fn)) {                                                                                            \
@@ -258,7 +258,7 @@ nvdb_status launch_scores_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, const float
   if constexpr (exact_img_shape<DT, D>()) {                                                                                        \
     if (c->opt_exact_img && c->opt_exact_lds != 2 && nq >= 64 && c->dim == D && q0 == 0) {                                         \
       const uint32_t gy = nq / 64;                                                                                                 \
-      uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);                                  \
+      uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu)) / gy);                                  \
       P = std::max<uint32_t>(1, std::min(P, std::max<uint32_t>(1, tiles / 8)));                                                    \
       const void* fn = reinterpret_cast<const void*>(exact_mfma_img_kernel<DT, D, true>);                                          \
       if (!c->lds_attr_set.count(fn)) {                                                                                            \
@@ -280,7 +280,7 @@ nvdb_status launch_scores_exact_mfma(nvdb_hip_ctx* c, hipStream_t s, const float
   if (q0 >= nq) return NVDB_OK;
   const uint32_t nr = nq - q0;
   const uint32_t gy = (nr + 63) / 64;
-  uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu) + gy - 1) / gy);
+  uint32_t P = std::max<uint32_t>(1, (2u * static_cast<uint32_t>(c->num_cu)) / gy);
   P = std::max<uint32_t>(1, std::min(P, tiles / 8));
   const dim3 grid(P, gy);
   const float* qr = q32 + static_cast<size_t>(q0) * c->dim;
