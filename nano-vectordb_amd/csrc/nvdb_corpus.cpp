@@ -337,6 +337,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "zero_copy") { c->opt_zero_copy = value ? 1 : 0; }
   else if (k == "exact_mfma") { c->opt_exact_mfma = value ? 1 : 0; }
   else if (k == "exact_img") { c->opt_exact_img = value ? 1 : 0; }
+  else if (k == "exact_prescan") { c->opt_exact_prescan = value ? 1 : 0; }
   else if (k == "exact_wgs") { if (value < 1 || value > 16) return fail(c, NVDB_ERR_INVALID, "exact_wgs must be in [1,16]"); c->opt_exact_wgs = value; }
   else if (k == "exact_lds") { if (value < 0 || value > 2) return fail(c, NVDB_ERR_INVALID, "exact_lds must be 0, 1 or 2"); c->opt_exact_lds = value; }
   else if (k == "time_launches") { c->opt_time_launches = value ? 1 : 0; }

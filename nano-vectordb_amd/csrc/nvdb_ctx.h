@@ -102,6 +102,7 @@ struct nvdb_hip_ctx {
   int64_t opt_exact_wgs = 1;                       // exact MFMA SCAN kernels: workgroups per CU in all (one is resident at a time).  1 = a single round: every workgroup pays the start-up of its
                                                    // top-k lists (the first ~150 tiles of a stream take the insertion path) once, and the grid (wgs * CUs / query groups, rounded DOWN) never leaves
                                                    // a partly filled last round -- 2, the value of round 3, cost 5-30 % (profiles/r04_exact_wgs_sweep.txt: 128 queries 67 -> 90 TFLOP/s)
+  int64_t opt_exact_prescan = 1;                   // path 1, more than 8 queries, >= 1M rows: scan the first 1/64 of the rows on its own and start the rest with its exact k-th best scores as the bar
   int64_t opt_exact_mfma = 1;                      // exact fp32-order scores on the fp32 matrix cores where the shape allows (kernels_exact_mfma.h); 0: VALU kernels only
   int64_t opt_rescore8 = 2;                        // rescore kernel: 0 lane per candidate, 1 eight lanes per candidate, 2 = 1 + rows staged through LDS
 

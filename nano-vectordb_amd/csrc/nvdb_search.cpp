@@ -134,8 +134,22 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
     return search_largek(c, s, dev_q, nq, k, dev_out_ids, dev_out_scores);
   }
   if (path == 1) {
-    if ((st = launch_scan_exact(c, s, 0, n, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
-    c->stats.chunks = 1; c->stats.rows_scanned = c->n;
+    // Two launches on big corpora (round 4): every workgroup of the scan starts with empty top-k lists, and until a list has warmed up
+    // nearly every tile takes the serial insertion path (~0.65 ms per round at 64 queries: profiles/r04_exact_wgs_sweep.txt).  So the
+    // first 1/64 of the rows is scanned on its own, a select turns it into the exact k-th best score per query (slack 0: the k best
+    // stay in the list), and the scan of the other 63/64 starts with that bar: a row reaches a list only if it beats it.  Same lists,
+    // same final select, same results.  (Only where the MFMA scan runs: more than 8 queries; the VALU kernel's lists warm up per wave.)
+    const uint32_t head = (c->opt_exact_prescan && nq > 8 && n >= (1u << 20)) ? std::max<uint32_t>(1u << 15, (n >> 6) & ~255u) : 0u;
+    if (head) {
+      if ((st = launch_scan_exact(c, s, 0, head, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
+      if ((st = launch_select(c, s, nq, cap, k_eff, nullptr, 0, nullptr, nullptr, 0))) return st;
+      if ((st = launch_scan_exact(c, s, head, n, dev_q, nq, k_eff, static_cast<const float*>(c->thr.p), cap, k_eff))) return st;
+      c->stats.chunks = 2;
+    } else {
+      if ((st = launch_scan_exact(c, s, 0, n, dev_q, nq, k_eff, nullptr, cap, 0))) return st;
+      c->stats.chunks = 1;
+    }
+    c->stats.rows_scanned = c->n;
     return launch_select(c, s, nq, cap, k_eff, nullptr, final_mode, dev_out_ids, dev_out_scores, k);
   }
 

@@ -33,6 +33,7 @@ for ci in range(cases):
     if rs.rand() < 0.2: opts["exact_mfma"] = 0
     if rs.rand() < 0.3: opts["exact_lds"] = int(rs.choice([0, 2]))
     if rs.rand() < 0.25: opts["exact_img"] = 0
+    if rs.rand() < 0.2: opts["exact_wgs"] = int(rs.choice([2, 3]))
     if rs.rand() < 0.25: opts["fuse"] = 0
     if rs.rand() < 0.25: opts["zero_copy"] = 0
     if rs.rand() < 0.2 and tag != "i8": opts["boot_tiles"] = int(rs.choice([96, 256, 300]))
@@ -51,7 +52,7 @@ for ci in range(cases):
             ok = ok and np.array_equal(ei[qi], oi[0]) and np.array_equal(es[qi].view(np.uint32), os_[0].view(np.uint32))
     except Exception as e:
         ok = False; st = {"error": str(e)}
-    for k_ in opts: ctx.set_option(k_, {"tile_permute": 1, "chunk_growth": 0, "mfma_boot": 1, "sibling_sync": 1, "xcd_balance": 1, "i8_defer": 0, "i8_lo_bits": 7, "boot_tiles": 0, "exact_mfma": 1, "exact_lds": 1, "exact_img": 1, "fuse": 1, "zero_copy": 1}[k_])
+    for k_ in opts: ctx.set_option(k_, {"tile_permute": 1, "chunk_growth": 0, "mfma_boot": 1, "sibling_sync": 1, "xcd_balance": 1, "i8_defer": 0, "i8_lo_bits": 7, "boot_tiles": 0, "exact_mfma": 1, "exact_lds": 1, "exact_img": 1, "exact_wgs": 1, "fuse": 1, "zero_copy": 1}[k_])
     ctx.set_option("path", 0)
     if not ok:
         fails += 1
