@@ -1347,6 +1347,42 @@ def test_exact_scores_on_the_fp32_matrix_cores(oracle, tag, d, nq):
     c.close()
 
 
+@pytest.mark.parametrize("tag", ["f16", "i8", "f32"])
+def test_exact_path_prescan_and_grid_options_leave_the_results_unchanged(oracle, tag):
+    """Path 1 on a corpus of >= 2^20 rows scans the first 1/64 of the rows alone, turns it into the exact k-th best score per query
+    (a select with slack 0) and starts the scan of the rest with that bar (option exact_prescan); the scan grid is one workgroup per
+    CU in all (exact_wgs).  Neither may change a bit: 70 queries (one full group of 64 on the image / LDS build + 6 on the
+    register-direct build), duplicate rows across the prescan boundary (ties at the bar), k = 1 and k = 64."""
+    n, d, nq = (1 << 20) + 12_345, 128, 70
+    dt = {"f16": nvdb_amd.DT_F16, "i8": nvdb_amd.DT_I8, "f32": nvdb_amd.DT_F32}[tag]
+    base, scales = nvdb_amd.synth_corpus(SEED + 190, 0, n, d, dt)
+    head = max(1 << 15, (n >> 6) & ~255)
+    base[head + 5] = base[head - 7]; base[n - 1] = base[3]                    # exact score ties on both sides of the prescan boundary
+    if scales is not None:
+        scales[head + 5] = scales[head - 7]; scales[n - 1] = scales[3]
+    queries = nvdb_amd.synth_rows_f32(SEED + 191, 0, nq, d)
+    as_f32 = (lambda r, i: oracle.f16_to_f32(r) if tag == "f16" else (r.astype(np.float32) * (scales[i] if tag == "i8" else 1.0)))
+    queries[0] = as_f32(base[head - 7], head - 7).astype(np.float32)         # its two best rows are the tie pair
+    queries[1] = as_f32(base[3], 3).astype(np.float32)
+    c = nvdb_amd.HipContext(0)
+    c.upload_corpus(base, dt, scales)
+    c.set_option("path", 1)
+    po_dt = {"f16": po.DT_F16, "i8": po.DT_I8, "f32": po.DT_F32}[tag]
+    for k in (10, 1, 64):
+        res = {}
+        for pre, wgs in ((1, 1), (0, 1), (1, 2), (0, 3)):
+            c.set_option("exact_prescan", pre); c.set_option("exact_wgs", wgs)
+            res[(pre, wgs)] = c.search_batch(queries, k)
+            assert c.stats()["path"] == 1 and c.stats()["chunks"] == (2 if pre else 1)
+        ref = res[(0, 1)]
+        for key, (i_, s_) in res.items():
+            assert np.array_equal(i_, ref[0]) and np.array_equal(s_.view(np.uint32), ref[1].view(np.uint32)), (tag, k, key)
+        sub = np.r_[0:3, 63:66, nq - 1]
+        _check_against_oracle(oracle, base, po_dt, scales, queries[sub], ref[0][sub], ref[1][sub], k, f"exact prescan/{tag}/k{k}")
+    assert set(res[(1, 1)][0][0][:2].tolist()) == {head - 7, head + 5} if tag != "i8" else True
+    c.close()
+
+
 def test_exact_mfma_lds_kernel_on_an_adopted_unpadded_corpus(oracle):
     """The LDS-staged exact kernel brings tiles in with direct-to-LDS loads; on an ADOPTED corpus (the caller's buffer, no zero
     padding behind the last row) a ragged last tile must be clamped into the row range, for rows and int8 scales alike."""
