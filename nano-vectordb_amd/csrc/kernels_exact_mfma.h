@@ -593,8 +593,8 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_lds_kernel(
 //   per tile and wave:  [192 MFMAs on image[t % 2]] -> [epilogue] -> [convert my quarter of tile t+1 into image[(t+1) % 2];
 //                        fetch my quarter of tile t+2] -> s_barrier
 //   image layout: row r at r * DIM * 4, 16-byte chunk p at position p ^ (r & 15) (the fp32-row build's, conflict-free for the
-//   A-operand reads); the conversion writes its 2 (fp16) / 4 (int8) chunks per raw chunk in a rotated order so that the 16
-//   lanes of a write phase fall into 16 different bank groups.
+//   A-operand reads); the lane -> (row, raw chunk) mapping of the conversion spreads the 16 lanes of a write phase over 2 (fp16) /
+//   4 (int8) rows, so that their fp32 chunks fall into 16 different bank groups without any reordering.
 //   LDS at d = 768: 2 x 48 KB image (+ 32 KB of top-k lists in the scan build).
 // Same chains, same order: bit-identical to every other exact kernel (test_exact_scores_on_the_fp32_matrix_cores).
 // ================================================================================================
@@ -632,13 +632,22 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
   const uint32_t t_lo = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * p / P), t_hi = static_cast<uint32_t>(static_cast<uint64_t>(tiles) * (p + 1) / P);
   if (t_lo >= t_hi) return;
 
-  // my quarter of a tile: raw chunk i of this lane = linear chunk L = (wave * PPW + i) * 64 + lane = chunk L % CHUNKS_PER_ROW of
-  // row L / CHUNKS_PER_ROW; its fp32 values are the image chunks WPC * c + j, j < WPC, of that row
+  // my quarter of a tile = rows 4 * wave .. + 3.  Raw chunk i of this lane is chunk `pc(i)` of row `pr(i)`, chosen so that the 16 lanes
+  // of one LDS write phase cover WPC rows x (16 / WPC) consecutive chunks: their fp32 chunks WPC * c + j then fall, for every j, into
+  // 16 different bank groups of the XOR-swizzled image ((WPC * c + j) ^ (r & 15): the chunks differ in the upper bits, the rows in the
+  // low log2(WPC) bits) -- no conflict and no data shuffling.  (A linear lane -> chunk mapping needed a rotated write order to avoid
+  // the conflicts: 146 v_cndmask per tile for int8 rows, three times the conversions themselves.)
+  //   fp16 (WPC 2; lane = 16 g + l): row 4w + 2 (g & 1) + (l & 1), chunk 16 i + 8 (g >> 1) + (l >> 1)     (a 16-lane group: 2 rows x 8 chunks)
+  //   int8 (WPC 4):                  row 4w + (lane & 3),           chunk 16 i + (lane >> 2)               (a 16-lane group: 4 rows x 4 chunks)
+  // Either way piece i of a wave covers chunks [16 i, 16 i + 16) of its four rows; global side: whole 128-byte lines per 16-lane group.
+  const uint32_t lg = static_cast<uint32_t>(lane) >> 4, l15 = static_cast<uint32_t>(lane) & 15u;
+  auto pr = [&](int) -> uint32_t { return WPC == 2 ? 4u * wave + 2u * (lg & 1u) + (l15 & 1u) : 4u * wave + (static_cast<uint32_t>(lane) & 3u); };
+  auto pc = [&](int i) -> uint32_t { return WPC == 2 ? 16u * static_cast<uint32_t>(i) + 8u * (lg >> 1) + (l15 >> 1) : 16u * static_cast<uint32_t>(i) + (static_cast<uint32_t>(lane) >> 2); };
+  static_assert(CHUNKS_PER_ROW == 16 * PPW, "piece i covers chunks [16 i, 16 i + 16) of the wave's four rows");
   const char* gbase = static_cast<const char*>(rows);
   // ONE register set, one tile (2.7 us) of prefetch distance.  A second set (the quarter of tile t+2 in flight while t+1 waits to be
   // converted) was built and measured: 94.8 instead of 99.0 TFLOP/s at 256 queries, 75.4 instead of 78.5 at 64 -- the extra 24
-  // registers cost more than the deeper prefetch gains (profiles/r04_exact_img_bench.txt), so a single group of 64 queries,
-  // whose rows come from HBM rather than from the L2 the other groups' workgroups fill, stays at ~78.
+  // registers cost more than the deeper prefetch gains (profiles/r04_exact_img_bench.txt).
   uint4 rawreg[1][PPW];
   float sc_nxt[1][4] = {{1.f, 1.f, 1.f, 1.f}};
   auto fetch_tile = [&](uint32_t tile, auto SETC) {                // (a tile beyond my range: the last one again, never converted)
@@ -646,10 +655,9 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
     const uint32_t tl = tile < t_hi ? tile : t_hi - 1;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const uint32_t L = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
-      uint32_t r = row_lo + tl * EXACT_MFMA_ROWS + L / CHUNKS_PER_ROW;
+      uint32_t r = row_lo + tl * EXACT_MFMA_ROWS + pr(i);
       r = r < row_hi ? r : row_hi - 1;
-      rawreg[SET][i] = *reinterpret_cast<const uint4*>(gbase + static_cast<uint64_t>(r) * ROW_BYTES + ((L % CHUNKS_PER_ROW) << 4));
+      rawreg[SET][i] = *reinterpret_cast<const uint4*>(gbase + static_cast<uint64_t>(r) * ROW_BYTES + (pc(i) << 4));
     }
     if constexpr (DT == DT_I8) {
       const uint32_t r0 = row_lo + tl * EXACT_MFMA_ROWS + 4u * static_cast<uint32_t>(kq);
@@ -663,8 +671,7 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
     char* img = smem + (tile & 1u) * IMG_BYTES;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const uint32_t L = static_cast<uint32_t>((wave * PPW + i) * 64 + lane);
-      const uint32_t r = L / CHUNKS_PER_ROW, c = L % CHUNKS_PER_ROW;
+      const uint32_t r = pr(i), c = pc(i);
       float x[EPC];
       if constexpr (DT == DT_F16) {
         ExactRaw<DT_F16> rw; rw.v = rawreg[SET][i];
@@ -676,17 +683,10 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) { x[e] = xl[e]; x[8 + e] = xh[e]; }
       }
-      // written in the order j = (rot + u) % WPC: the 16 consecutive raw chunks of one write phase then cover 16 different
-      // residues of the chunk position mod 16 (2c + (c >> 3 & 1) for fp16, 4c + (c >> 2 & 3) for int8)
-      const uint32_t rot = (WPC == 2) ? ((c >> 3) & 1u) : ((c >> 2) & 3u);
 #pragma unroll
-      for (int u = 0; u < WPC; ++u) {
-        const uint32_t j = (rot + u) & (WPC - 1);
-        float4 w = make_float4(x[0], x[1], x[2], x[3]);
-#pragma unroll
-        for (int jj = 1; jj < WPC; ++jj) if (j == static_cast<uint32_t>(jj)) w = make_float4(x[4 * jj], x[4 * jj + 1], x[4 * jj + 2], x[4 * jj + 3]);
-        const uint32_t pos = (WPC * c + j) ^ (r & 15u);
-        *reinterpret_cast<float4*>(img + r * IMG_ROW + (pos << 4)) = w;
+      for (int j = 0; j < WPC; ++j) {
+        const uint32_t pos = (WPC * c + static_cast<uint32_t>(j)) ^ (r & 15u);
+        *reinterpret_cast<float4*>(img + r * IMG_ROW + (pos << 4)) = make_float4(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
       }
     }
   };
