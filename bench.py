@@ -766,6 +766,28 @@ def main():
                                       "score_delta_rankwise": {"max": float(d_rank.max()), "mean": float(d_rank.mean()),
                                                                "what": "|j-th best int8 score - j-th best fp32 score| over all queries and ranks"},
                                       "quantiser": "per-row scale = max|x|/127, lrint, clamp [-127,127] (reference apps/nvdb_quantize_i8.cpp:71-80)"}
+            # (2b) NOT a BASELINE config and never `value`: the same fp16 corpus FILTERED through an int8 shadow of itself (option q8_shadow, off by
+            #      default: + N x d bytes of HBM) -- integer MFMAs over half the bytes, survivors re-scored from the fp16 rows, same ids and score bits
+            cq = nvdb_amd.HipContext(local_rank)
+            cq.set_option("q8_shadow", 1)
+            cq.generate_corpus(SEED, N, D, nvdb_amd.DT_F16)
+            shadow = {}
+            for bb in (B, 64):
+                el = timed_passes(cq, bb)
+                shadow[f"batch{bb}"] = {"qps": bb / el, "ms_per_pass": el * 1e3, "candidates_per_query": timed_passes.last_stats["candidates"] / bb,
+                                        "hbm_GBps_shadow_bytes": N * (D + 4) / 1e9 / el}
+            strm = torch.cuda.current_stream().cuda_stream
+            cq.search_batch_dev(qdev[:B].data_ptr(), B, K, out_ids.data_ptr(), out_sc.data_ptr(), strm)
+            torch.cuda.synchronize(); cq.search_check()
+            qi_, qs_ = out_ids.cpu().numpy().copy(), out_sc.cpu().numpy().copy()
+            ctx.search_batch_dev(qdev[:B].data_ptr(), B, K, out_ids.data_ptr(), out_sc.data_ptr(), strm)
+            torch.cuda.synchronize(); ctx.search_check()
+            same = bool(np.array_equal(qi_, out_ids.cpu().numpy()) and np.array_equal(qs_.view(np.uint32), out_sc.cpu().numpy().view(np.uint32)))
+            cq.close()
+            extras["fp16_corpus_int8_filter_shadow"] = {"workload": f"fp16 flat-scan top-{K}, N={N} d={D}: filter on an int8 shadow of the fp16 rows (option q8_shadow=1, off by default), exact rescore from the fp16 rows",
+                                                        **shadow, "identical_to_the_fp16_filter": same, "extra_hbm_bytes": N * (D + 4)}
+            if not same:
+                raise RuntimeError("q8_shadow: results differ from the fp16 filter path")
             # (3) BASELINE configs[4]: exact-L2 refine, N=2.9M fp16, Q=10000, R=1024, K=10, synthetic candidates
             NR, QR, RR = min(N, 2_900_000), 10_000, 1024
             cr = nvdb_amd.HipContext(local_rank)

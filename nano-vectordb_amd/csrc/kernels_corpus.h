@@ -77,6 +77,42 @@ static __global__ __launch_bounds__(256) void shadow_i8_kernel(const signed char
   }
 }
 
+// int8 FILTER shadow of an fp16 / fp32 corpus (option q8_shadow): the rows quantised per row by the reference's own rule
+// (apps/nvdb_quantize_i8.cpp:71-80: scale = max|x| / 127, rint(x / scale), clamp +-127), rows zero-padded to sdim, plus -- what turns
+// a lossy copy into a usable FILTER -- the largest quantisation residual ||x - scale * x_q||_2 over all rows (float bits via atomicMax):
+// |<q, x> - <q, scale * x_q>| <= ||q|| * that, which the query prep adds to the filter's error bound.  One wave per row.
+// out_bits[0] = max residual norm (slightly inflated), out_bits[1] = 1 if a row held a non-finite value (no shadow then).
+template <typename SrcT>
+__global__ __launch_bounds__(256) void shadow_q8_kernel(const SrcT* __restrict__ src, signed char* __restrict__ dst, float* __restrict__ dst_scales,
+                                                        uint64_t n, uint32_t dim, uint32_t sdim, uint32_t* __restrict__ out_bits) {
+  const int lane = threadIdx.x & 63;
+  float wres = 0.f;
+  bool bad = false;
+  for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); r < n; r += static_cast<uint64_t>(gridDim.x) * 4) {
+    const SrcT* row = src + r * dim;
+    float mx = 0.f;
+    for (uint32_t c = lane; c < dim; c += 64) mx = fmaxf(mx, fabsf(static_cast<float>(row[c])));
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (!(mx < 3.0e38f)) bad = true;
+    const float scale = mx > 0.f ? mx / 127.f : 1.f;
+    const float inv = 1.0f / scale;
+    float ss = 0.f;
+    signed char* out = dst + r * sdim;
+    for (uint32_t c = lane; c < sdim; c += 64) {
+      float qv = 0.f, x = 0.f;
+      if (c < dim) { x = static_cast<float>(row[c]); qv = fminf(fmaxf(rintf(x * inv), -127.f), 127.f); }
+      out[c] = static_cast<signed char>(static_cast<int>(qv));
+      const float d = x - qv * scale;
+      ss = __builtin_fmaf(d, d, ss);
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) dst_scales[r] = scale;
+    wres = fmaxf(wres, sqrtf(ss) * 1.0001f);
+  }
+  if (lane == 0 && wres > 0.f) atomicMax(out_bits, __builtin_bit_cast(uint32_t, wres));
+  if (lane == 0 && (bad || !(wres < 3.0e38f))) out_bits[1] = 1u;
+}
+
 // max over rows of the (dequantised) L2 norm, slightly inflated; result as float bits via atomicMax
 template <int DT>
 __global__ __launch_bounds__(256) void row_norm_max_kernel(const void* __restrict__ rows, const float* __restrict__ scales,

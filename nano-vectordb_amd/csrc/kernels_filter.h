@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256, 1) void filter_f16_k2_kernel(
 // would drain the stream -- is needed in the loop).
 // ================================================================================================
 static __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __restrict__ q32, uint32_t nq, uint32_t dim, uint32_t sdim,
-                                                      float max_row_norm, signed char* __restrict__ qhi,
+                                                      float max_row_norm, float corpus_resid, signed char* __restrict__ qhi,
                                                       signed char* __restrict__ qlo, float* __restrict__ qscale,
                                                       float* __restrict__ qinv, float* __restrict__ ebound,
                                                       float* __restrict__ slack, float* __restrict__ qdelta, uint32_t* __restrict__ overflow, uint32_t lo_bits, PrepInit pi) {
@@ -1021,7 +1021,8 @@ static __global__ __launch_bounds__(256) void prep_q8_kernel(const float* __rest
 
     const float nrm = sqrtf(ss) * 1.0001f;
     // quantisation: |dq_i| <= 0.5 s_q (+ the rounding of q*isq: <= 2^-23 |q_i|); fp32 chains: 1e-5 ||q||
-    const float eb = (0.5005f * sqrtf(static_cast<float>(dim)) * sq + 1.0e-5f * nrm) * max_row_norm * 1.001f + 1e-30f;
+    // corpus_resid > 0: the rows streamed are an int8 SHADOW of an fp16 / fp32 corpus (shadow_q8_kernel): |<q, x> - <q, x_shadow>| <= ||q|| * max ||x - x_shadow||
+    const float eb = (0.5005f * sqrtf(static_cast<float>(dim)) * sq + 1.0e-5f * nrm) * max_row_norm * 1.001f + nrm * corpus_resid * 1.001f + 1e-30f;
     qscale[q] = isq; qinv[q] = sq; ebound[q] = eb; slack[q] = 2.f * eb;
     if (!(ss < 3.0e38f)) { overflow[q] = 1u; ebound[q] = -1.f; }     // NaN / infinite query: exact path (see prep_q16_kernel)
   }

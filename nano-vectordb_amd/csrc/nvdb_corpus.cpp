@@ -17,6 +17,7 @@ void free_corpus(nvdb_hip_ctx* c) {
   if (c->shadow8_scales) { (void)hipFree(c->shadow8_scales); c->shadow8_scales = nullptr; }
   c->rows = nullptr; c->scales = nullptr; c->owned = false; c->n = 0; c->dim = 0; c->fdim = 0; c->dtype = 0; c->max_norm = 0.f;
   c->cap_hint = 0;
+  c->q8shadow = false; c->resid_max = 0.f; c->filter_max_norm = 0.f;
 }
 
 nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
@@ -39,6 +40,41 @@ nvdb_status compute_max_norm(nvdb_hip_ctx* c) {
   // fp32 corpus, or fp16 with another dim <= 1536: an fp16 shadow copy, rows zero-padded to the next instantiated
   // dim (skipped when values would overflow a half).  int8: its own instantiations, no shadow.
   c->fdim = c->dim;
+  c->filter_max_norm = c->max_norm;
+  c->q8shadow = false; c->resid_max = 0.f;
+  // Option q8_shadow (off by default): an fp16 / fp32 corpus is FILTERED through an int8 copy of itself -- half (a quarter) of the bytes per
+  // row and integer MFMAs at twice the fp16 rate; the rows' quantisation residual joins the filter's error bound and every survivor is
+  // re-scored from the ORIGINAL rows, so ids and scores stay bit-exact.  Costs n x dim bytes of HBM.
+  if (c->opt_q8_shadow && c->dtype != NVDB_DTYPE_I8 && i8_filter_dim(c->dim)) {
+    const uint32_t sdim = c->dim;
+    const size_t count = static_cast<size_t>(c->n) * sdim, pad = static_cast<size_t>(PAD_ROWS) * sdim + 4096;
+    const size_t n_pad = (static_cast<size_t>(c->n) + PAD_ROWS - 1) / PAD_ROWS * PAD_ROWS + PAD_ROWS;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow8), count + pad));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->shadow8_scales), n_pad * 4));
+    HIPCHK(c, hipMemsetAsync(c->shadow8 + count, 0, pad, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->shadow8_scales, 0, n_pad * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(bits, 0, 8, c->stream));
+    if (c->dtype == NVDB_DTYPE_F32) shadow_q8_kernel<float><<<grid, 256, 0, c->stream>>>(static_cast<const float*>(c->rows), c->shadow8, c->shadow8_scales, c->n, c->dim, sdim, bits);
+    else shadow_q8_kernel<_Float16><<<grid, 256, 0, c->stream>>>(static_cast<const _Float16*>(c->rows), c->shadow8, c->shadow8_scales, c->n, c->dim, sdim, bits);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hb, bits, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (hb[1] == 0) {
+      std::memcpy(&c->resid_max, &hb[0], 4);
+      // row norms of the shadow (what the int8 kernels stream): the query side of the bound and the lo-plane margin are priced with them
+      HIPCHK(c, hipMemsetAsync(bits, 0, 8, c->stream));
+      row_norm_max_kernel<DT_I8><<<grid, 256, 0, c->stream>>>(c->shadow8, c->shadow8_scales, c->n, sdim, bits);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(hb, bits, 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      std::memcpy(&c->filter_max_norm, &hb[0], 4);
+      c->q8shadow = true;
+      c->i8_scales_signed = false;
+      return NVDB_OK;                                          // (no fp16 shadow beside it)
+    }
+    (void)hipFree(c->shadow8); c->shadow8 = nullptr;           // a non-finite value in the corpus: no shadow, the usual routing
+    (void)hipFree(c->shadow8_scales); c->shadow8_scales = nullptr;
+  }
   if (c->dtype != NVDB_DTYPE_I8 && c->dim <= F16_FILTER_MAX_DIM && !(c->dtype == NVDB_DTYPE_F16 && f16_filter_dim(c->dim)) && c->opt_f32_shadow) {
     uint32_t sdim = 128;
     while (!f16_filter_dim(sdim) || sdim < c->dim) sdim += 128;
@@ -311,6 +347,7 @@ nvdb_status nvdb_hip_set_option(nvdb_hip_ctx* c, const char* key, int64_t value)
   else if (k == "sync_lead") { if (value < 1) return fail(c, NVDB_ERR_INVALID, "sync_lead must be >= 1"); c->opt_sync_lead = value; }
   else if (k == "sibling_sync") { c->opt_sibling_sync = value ? 1 : 0; }
   else if (k == "f32_shadow") { c->opt_f32_shadow = value ? 1 : 0; }
+  else if (k == "q8_shadow") { c->opt_q8_shadow = value ? 1 : 0; }
 #ifdef NVDB_HIP_DEV
   else if (k == "mfma16") { c->opt_mfma16 = value ? 1 : 0; }
   else if (k == "i8_wide") { c->opt_i8_wide = value ? 1 : 0; }

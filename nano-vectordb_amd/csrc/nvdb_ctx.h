@@ -75,7 +75,11 @@ struct nvdb_hip_ctx {
   uint64_t row_base = 0;
   float max_norm = 0.f;
   bool i8_scales_signed = false;                   // int8 corpus with a negative or NaN row scale: the in-loop second-stage build (no biased accumulators)
-  signed char* shadow8 = nullptr;                  // int8 corpus with a dim the kernels are not instantiated for: rows zero-padded to fdim
+  signed char* shadow8 = nullptr;                  // int8 corpus with a dim the kernels are not instantiated for: rows zero-padded to fdim; or (q8shadow) the int8 FILTER shadow of an fp16 / fp32 corpus
+  bool q8shadow = false;                           // fp16 / fp32 corpus filtered through an int8 shadow (option q8_shadow): the int8 MFMA kernels stream shadow8, every survivor is re-scored from the original rows
+  float filter_max_norm = 0.f;                     // max row norm of what the int8 filter streams (== max_norm for an int8 corpus; the shadow's for q8shadow)
+  float resid_max = 0.f;                           // q8shadow: largest ||x - scale * x_q|| over the rows -- the corpus side of the filter's error bound
+  int64_t opt_q8_shadow = 0;                       // set before the corpus is loaded: build the int8 filter shadow for fp16 / fp32 corpora whose dim the int8 kernels take
   float* shadow8_scales = nullptr;                 // ... and its scales in a buffer padded to whole tiles
   _Float16* shadow16 = nullptr;                    // fp16 copy streamed by the MFMA filter (fp32 corpus and/or padded dim)
   uint32_t fdim = 0;                               // dim the filter kernels run at (>= dim; == dim without padding)
@@ -196,7 +200,10 @@ inline const _Float16* filter_rows_f16(const nvdb_hip_ctx* c) {
   return c->shadow16 ? c->shadow16 : static_cast<const _Float16*>(c->rows);
 }
 
+// the int8 MFMA kernels do the filtering: an int8 corpus, or an fp16 / fp32 corpus with an int8 filter shadow
+inline bool filter_is_i8(const nvdb_hip_ctx* c) { return c->dtype == NVDB_DTYPE_I8 || c->q8shadow; }
 inline bool filter_supported(const nvdb_hip_ctx* c) {
+  if (c->q8shadow) return true;
   if (c->dtype == NVDB_DTYPE_F16) return f16_filter_dim(c->dim) || c->shadow16 != nullptr;
   if (c->dtype == NVDB_DTYPE_F32) return c->shadow16 != nullptr;
   if (c->dtype == NVDB_DTYPE_I8) return i8_filter_dim(c->dim) || c->shadow8 != nullptr;
@@ -204,12 +211,12 @@ inline bool filter_supported(const nvdb_hip_ctx* c) {
 }
 
 // int8: the two-stage kernel (hi plane resident, lo plane on demand); option i8_wide = 0 selects the two-plane kernel
-inline bool i8_two_stage(const nvdb_hip_ctx* c) { return c->dtype == NVDB_DTYPE_I8 && c->opt_i8_wide; }
+inline bool i8_two_stage(const nvdb_hip_ctx* c) { return filter_is_i8(c) && c->opt_i8_wide; }
 
 // NB = 32-query blocks per wave: 1 for nq <= 128 (HBM-bound regime) and for the two-plane int8 kernel, else 2
 inline uint32_t filter_nb(const nvdb_hip_ctx* c, uint32_t nq) {
-  if (c->dtype == NVDB_DTYPE_I8 && (!i8_two_stage(c) || c->fdim > 768)) return 1u;   // two-plane kernel; dims > 768: 32 queries per wave
-  if (c->dtype != NVDB_DTYPE_I8 && c->fdim > 768) return 1u;          // 16-row-tile build: 128 queries per workgroup
+  if (filter_is_i8(c) && (!i8_two_stage(c) || c->fdim > 768)) return 1u;   // two-plane kernel; dims > 768: 32 queries per wave
+  if (!filter_is_i8(c) && c->fdim > 768) return 1u;          // 16-row-tile build: 128 queries per workgroup
   return nq <= 128 ? 1u : 2u;
 }
 

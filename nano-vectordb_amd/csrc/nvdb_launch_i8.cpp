@@ -6,7 +6,9 @@
 namespace nvdbhip {
 
 nvdb_status launch_prep_q8(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint32_t nq, uint32_t nq_pad, const PrepInit& pinit) {
-  prep_q8_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->fdim, c->max_norm, static_cast<signed char*>(c->q16.p),
+  // (filter_max_norm: row norms of what the int8 kernels stream -- the corpus itself, or the int8 filter shadow of an fp16 / fp32 corpus,
+  //  whose quantisation residual resid_max joins the error bound)
+  prep_q8_kernel<<<nq_pad, 256, 0, s>>>(dev_q, nq, c->dim, c->fdim, c->filter_max_norm, c->q8shadow ? c->resid_max : 0.f, static_cast<signed char*>(c->q16.p),
                                         static_cast<signed char*>(c->q16.p) + static_cast<size_t>(nq_pad) * c->fdim,
                                         static_cast<float*>(c->qscale.p), static_cast<float*>(c->qinv.p),
                                         static_cast<float*>(c->ebound.p), static_cast<float*>(c->slack.p), static_cast<float*>(c->qdelta.p),

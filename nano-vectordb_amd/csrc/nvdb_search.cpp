@@ -57,11 +57,11 @@ ScatterArgs scatter_args(nvdb_hip_ctx* c, uint32_t cap, uint32_t trows) {
 
 nvdb_status launch_boot(nvdb_hip_ctx* c, hipStream_t s, uint32_t n0, uint32_t nq, uint32_t QT, uint32_t cap, uint32_t nb) {
   // (int8: the boot build is the 128-queries-per-workgroup kernel; same padded batch)
-  return c->dtype == NVDB_DTYPE_I8 ? launch_boot_i8(c, s, n0, nq, QT * nb, cap) : launch_boot_f16(c, s, n0, nq, QT, cap, nb);
+  return filter_is_i8(c) ? launch_boot_i8(c, s, n0, nq, QT * nb, cap) : launch_boot_f16(c, s, n0, nq, QT, cap, nb);
 }
 
 nvdb_status launch_filter(nvdb_hip_ctx* c, hipStream_t s, uint32_t row_lo, uint32_t row_hi, uint32_t nq, uint32_t QT, uint32_t cap) {
-  return c->dtype == NVDB_DTYPE_I8 ? launch_filter_i8(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_f16(c, s, row_lo, row_hi, nq, QT, cap);
+  return filter_is_i8(c) ? launch_filter_i8(c, s, row_lo, row_hi, nq, QT, cap) : launch_filter_f16(c, s, row_lo, row_hi, nq, QT, cap);
 }
 
 // Enqueue one whole search of nq (<= 2048) queries resident at dev_q.  No host synchronisation.
@@ -95,7 +95,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
                               c->fdim <= 768 && c->n >= 2ull * FILTER_ROWS * 8 * k_eff);
   if (wide_on_filter) cap = SELECT_MAX_CAP;
   // queries per filter workgroup: 256 / 128, or 64 on the K-split build (dims > 1536)
-  const uint32_t QPB = (c->dtype != NVDB_DTYPE_I8 && c->fdim > 1536) ? 64u : 128u * filter_nb(c, nq);
+  const uint32_t QPB = (!filter_is_i8(c) && c->fdim > 1536) ? 64u : 128u * filter_nb(c, nq);
   const uint32_t QT = (nq + QPB - 1) / QPB;
   const uint32_t nq_pad = QT * QPB;
 
@@ -160,14 +160,14 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   if ((st = ensure(c, c->ebound, nq_pad * 4))) return st;
   if ((st = ensure(c, c->slack, nq_pad * 4))) return st;
   if ((st = ensure(c, c->qdelta, nq_pad * 4))) return st;
-  if ((st = c->dtype == NVDB_DTYPE_I8 ? launch_prep_q8(c, s, dev_q, nq, nq_pad, pinit) : launch_prep_q16(c, s, dev_q, nq, nq_pad, pinit))) return st;
+  if ((st = filter_is_i8(c) ? launch_prep_q8(c, s, dev_q, nq, nq_pad, pinit) : launch_prep_q16(c, s, dev_q, nq, nq_pad, pinit))) return st;
   const float* slack = static_cast<const float*>(c->slack.p);
   // Whole tiles: a corpus this library allocated is zero-padded to a multiple of 32 rows (the padded rows are
   // dropped when the wave files its survivors); for an adopted corpus the ragged tail goes to the exact kernel.
   const bool padded = c->owned || c->shadow16 != nullptr || c->shadow8 != nullptr;          // a shadow copy is always ours, hence padded
   // chunk boundaries are whole tiles of the streaming kernel: 64 rows for the int8 two-stage kernel and for the m16
   // fp16 build at d <= 384, 32 otherwise
-  const bool f16_wide_tiles = c->dtype != NVDB_DTYPE_I8 && c->fdim <= 384 && filter_nb(c, nq) == 2 && c->opt_mfma16;
+  const bool f16_wide_tiles = !filter_is_i8(c) && c->fdim <= 384 && filter_nb(c, nq) == 2 && c->opt_mfma16;
   const uint32_t tile_rows = ((i8_two_stage(c) && c->fdim <= 768) || f16_wide_tiles) ? I8W_TILE_ROWS : FILTER_ROWS;
   const uint32_t n_al = padded ? (n + tile_rows - 1) / tile_rows * tile_rows : n / tile_rows * tile_rows;
   uint32_t r = 0;
@@ -241,7 +241,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
         else HIPCHK(c, hipEventCreate(e));
       }
       kl.flops = 2.0 * nq * static_cast<double>(std::min(hi, n) - r) * c->dim;   // algorithmic: real queries, real rows
-      kl.bytes = static_cast<double>(std::min(hi, n) - r) * (c->dtype == NVDB_DTYPE_I8 ? c->fdim + 4.0 : c->fdim * 2.0);   // rows streamed once
+      kl.bytes = static_cast<double>(std::min(hi, n) - r) * (filter_is_i8(c) ? c->fdim + 4.0 : c->fdim * 2.0);   // rows streamed once
       c->launch_e0 = kl.e0; c->launch_e1 = kl.e1;
     } else if (time_filter) {
       c->launch_e0 = get_event(c, ev); c->launch_e1 = get_event(c, ev + 1);
@@ -479,7 +479,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
       (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
       timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
       timing->threads = 256; timing->nwarps = 4; timing->K = k;
-      timing->shmem_bytes = part.path != 2 ? 0 : c->dtype == NVDB_DTYPE_I8 ? static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * c->fdim + 4096) : static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * 2;
+      timing->shmem_bytes = part.path != 2 ? 0 : filter_is_i8(c) ? static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * c->fdim + 4096) : static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * 2;
     }
     if (part.bound_violations) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated; results were recomputed on the exact path");
     return NVDB_OK;
@@ -536,7 +536,7 @@ nvdb_status nvdb_hip_search_batch(nvdb_hip_ctx* c, const float* queries, uint32_
     (void)hipEventElapsedTime(&timing->d2h_ms, e2, e3);
     timing->total_ms = timing->h2d_ms + timing->kernel_ms + timing->d2h_ms;
     timing->threads = 256; timing->nwarps = 4; timing->K = k;
-    timing->shmem_bytes = total.path != 2 ? 0 : c->dtype == NVDB_DTYPE_I8 ? static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * c->fdim + 4096) : static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * 2;
+    timing->shmem_bytes = total.path != 2 ? 0 : filter_is_i8(c) ? static_cast<size_t>(FILTER_STAGES_I8) * (FILTER_ROWS * c->fdim + 4096) : static_cast<size_t>(FILTER_STAGES) * FILTER_ROWS * c->fdim * 2;
   }
   if (total.bound_violations) return fail(c, NVDB_ERR_INTERNAL, "filter error bound violated; results were recomputed on the exact path");
   return NVDB_OK;

@@ -523,6 +523,81 @@ def test_filter_path_for_dims_up_to_1536(ctx, oracle, tag, d, nq):
     _check_against_oracle(oracle, base, po.DT_F16 if tag == "f16" else po.DT_F32, None, queries, res[2][0], res[2][1], k, f"bigdim/{tag}/d{d}")
 
 
+@pytest.mark.parametrize("tag,d,nq,k", [("f16", 768, 300, 10), ("f16", 768, 1, 10), ("f16", 384, 70, 10), ("f32", 768, 130, 10), ("f16", 1024, 64, 5),
+                                        ("f32", 512, 1024, 10), ("f16", 768, 40, 100)])
+def test_int8_filter_shadow_of_an_fp16_or_fp32_corpus_stays_exact(oracle, tag, d, nq, k):
+    """Option q8_shadow: an fp16 / fp32 corpus is FILTERED through an int8 copy of itself (the reference's per-row quantiser) on the
+    integer matrix cores; the rows' largest quantisation residual joins the filter's error bound and every survivor is re-scored from
+    the ORIGINAL rows.  Ids and score bits must equal the oracle's fp16 / fp32 answer, the self-check (|filter - exact| <= bound for
+    every survivor) must stay silent, and the exact path must agree for every query."""
+    n = 150_000 + 17
+    base32 = nvdb_amd.synth_rows_f32(SEED + 200, 0, n, d)                # unit-norm rows, like embeddings: every row quantises about equally well
+    base32[201] = 0.0
+    base32[100:140] *= (np.float32(10.0) ** np.random.RandomState(d).randint(-3, 1, size=(40, 1))).astype(np.float32)   # some much SHORTER rows
+    base, dt, scales = _as_dtype(oracle, base32, tag)
+    queries = nvdb_amd.synth_rows_f32(SEED + 201, 0, nq, d)
+    queries[0] = base32[300]
+    c = nvdb_amd.HipContext(0)
+    c.set_option("q8_shadow", 1)
+    c.upload_corpus(base, dt, scales)
+    ids, sc = c.search_batch(queries, k)
+    st = c.stats()
+    assert st["path"] == 2 and st["bound_violations"] == 0 and st["overflow_queries"] == 0, st
+    c.set_option("path", 1)
+    ei, es = c.search_batch(queries, k)
+    c.close()
+    assert np.array_equal(ids, ei) and np.array_equal(sc.view(np.uint32), es.view(np.uint32))
+    sub = np.unique(np.r_[0, nq // 2, nq - 1])
+    _check_against_oracle(oracle, base, dt, scales, queries[sub], ids[sub], sc[sub], k, f"q8 shadow/{tag}/d{d}")
+    # without the option the same corpus takes the fp16 filter: same answer
+    c2 = nvdb_amd.HipContext(0)
+    c2.upload_corpus(base, dt, scales)
+    i2, s2 = c2.search_batch(queries, k)
+    c2.close()
+    assert np.array_equal(ids, i2) and np.array_equal(sc.view(np.uint32), s2.view(np.uint32))
+
+
+def test_int8_filter_shadow_of_rows_that_quantise_badly_stays_exact(oracle):
+    """The corpus side of the shadow's error bound is ||q|| x the LARGEST quantisation residual of any row: one row with a dominant
+    element (coarse scale) or rows ten times longer than the rest widen the band for every query.  The lists then overflow and the host
+    API redoes the batch on the exact path -- slower, never wrong."""
+    n, d, nq, k = 120_000, 768, 50, 10
+    base32 = nvdb_amd.synth_rows_f32(SEED + 205, 0, n, d)
+    base32[100:140] *= np.float32(10.0)                                  # ten times longer rows
+    base32[200, 5] = np.float32(0.9)                                     # one dominant element
+    base = oracle.f32_to_f16(base32)
+    queries = nvdb_amd.synth_rows_f32(SEED + 206, 0, nq, d)
+    queries[0] = base32[200]
+    c = nvdb_amd.HipContext(0)
+    c.set_option("q8_shadow", 1)
+    c.upload_corpus(base, nvdb_amd.DT_F16)
+    ids, sc = c.search_batch(queries, k)
+    assert c.stats()["bound_violations"] == 0
+    c.close()
+    sub = np.r_[0:3, nq - 1]
+    _check_against_oracle(oracle, base, po.DT_F16, None, queries[sub], ids[sub], sc[sub], k, "q8 shadow/badly quantising rows")
+
+
+def test_int8_filter_shadow_with_near_duplicates_falls_back_but_stays_exact(oracle):
+    """Thousands of rows inside the (wider) error band of the int8 shadow: the candidate lists overflow, the host API redoes the batch with
+    the longest lists / on the exact path -- the answer stays the oracle's."""
+    n, d, nq, k = 200_000, 768, 20, 10
+    rs = np.random.RandomState(5)
+    centre = nvdb_amd.synth_rows_f32(SEED + 210, 0, 1, d)[0]
+    base32 = nvdb_amd.synth_rows_f32(SEED + 211, 0, n, d)
+    base32[:6000] = centre + np.float32(2e-4) * rs.randn(6000, d).astype(np.float32)       # 6000 near-duplicates of one direction
+    base = oracle.f32_to_f16(base32)
+    queries = nvdb_amd.synth_rows_f32(SEED + 212, 0, nq, d)
+    queries[0] = centre
+    c = nvdb_amd.HipContext(0)
+    c.set_option("q8_shadow", 1)
+    c.upload_corpus(base, nvdb_amd.DT_F16)
+    ids, sc = c.search_batch(queries, k)
+    assert c.stats()["bound_violations"] == 0
+    c.close()
+    _check_against_oracle(oracle, base, po.DT_F16, None, queries[:3], ids[:3], sc[:3], k, "q8 shadow/near-duplicates")
+
+
 @pytest.mark.parametrize("tag", ["f16", "i8"])
 def test_non_finite_queries_take_the_exact_path(ctx, oracle, tag):
     """A query with a NaN or an infinite element has no usable filter bound: it is flagged like a list overflow and
