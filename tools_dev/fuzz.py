@@ -21,6 +21,8 @@ for ci in range(cases):
     nq = int(rs.choice([1, 2, 31, 32, 33, 64, 65, 128, 129, 200, 256, 257, 700, 1024, 1100]))
     k = int(rs.choice([1, 3, 10, 10, 10, 33, 64, 64, 65, 100, 300, 1024, 1500]))      # > 64: wide k on the filter / the any-k path
     if n * dim > 400000 * 384: n = 400000 * 384 // dim
+    q8 = tag != "i8" and dim % 128 == 0 and 256 <= dim <= 1536 and rs.rand() < 0.35     # the int8 filter shadow (set before the corpus is loaded)
+    ctx.set_option("q8_shadow", 1 if q8 else 0)
     ctx.generate_corpus(1000 + ci, n, dim, DT[tag])
     q = nvdb_amd.synth_rows_f32(5000 + ci, 0, nq, dim)
     if rs.rand() < 0.3: q[0] *= np.float32(10.0 ** rs.uniform(-6, 6))
@@ -56,6 +58,6 @@ for ci in range(cases):
     ctx.set_option("path", 0)
     if not ok:
         fails += 1
-        print(f"FAIL case {ci}: {tag} n={n} dim={dim} nq={nq} k={k} opts={opts} stats={st}", flush=True)
+        print(f"FAIL case {ci}: {tag} n={n} dim={dim} nq={nq} k={k} q8_shadow={q8} opts={opts} stats={st}", flush=True)
 print(f"fuzz seed {seed}: {cases} cases, {fails} failures, {time.time() - t0:.1f} s", flush=True)
 sys.exit(1 if fails else 0)
