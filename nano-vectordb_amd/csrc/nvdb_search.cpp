@@ -114,7 +114,7 @@ nvdb_status search_core(nvdb_hip_ctx* c, hipStream_t s, const float* dev_q, uint
   // straight from pinned host memory); the exact and any-k paths have no prep launch: init_search_kernel, queries copied here.
   const bool filter_flow = path == 2 && !(k_wide && !wide_on_filter);
   const bool prep_inits = c->opt_fuse && filter_flow;
-  if (host_q && !prep_inits) { HIPCHK(c, hipMemcpyAsync(const_cast<float*>(dev_q), host_q, static_cast<size_t>(nq) * c->dim * 4, hipMemcpyHostToDevice, s)); host_q = nullptr; }
+  if (host_q && !prep_inits) { HIPCHK(c, hipMemcpyAsync(const_cast<float*>(dev_q), host_q, static_cast<size_t>(nq) * c->dim * 4, hipMemcpyDefault, s)); host_q = nullptr; }   // (host_q is the pinned block as the device addresses it)
   // (one query tile per stream has no siblings to keep in step: nothing to reset)
   if (!prep_inits) {
     if ((st = launch_init_search(c, s, nq_pad, QT > 1 ? prog_words : 0u))) return st;
