@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, 1) void scan_exact_mfma_kernel(
   uint32_t thr_id = 0xFFFFFFFFu, my_cnt = 0;
   const float gthr = (thr != nullptr && qi < nq) ? thr[qi] : NEG_INF;
   const bool real = qi < nq;
+  float quick = gthr;
 
   const char* gbase = static_cast<const char*>(rows);
   auto lane_ptr = [&](uint32_t tile) -> const char* {     // row (tile, m = lane % 16), clamped into the range; + this lane's K offset
@@ -208,15 +209,16 @@ __global__ __launch_bounds__(256, 1) void scan_exact_mfma_kernel(
 #pragma unroll
       for (int v = 0; v < 4; ++v) { s[v] = s[v] * sc_cur[v]; sc_cur[v] = sc_nxt[v]; }                           // simd_dot.cpp:198
     }
+    // one compare per tile and lane in front of the full test: a row can only enter with a score >= quick (= the bar handed in and,
+    // once this query's list is full, its k-th score; NaN scores never enter)
+    const float smax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    if (!__ballot(real && smax >= quick)) continue;
     bool pass[4];
-    bool any = false;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const uint32_t row = row0 + v;
       pass[v] = real && row < row_hi && s[v] >= gthr && (my_cnt < k || better(s[v], row, thr_s, thr_id));
-      any = any || pass[v];
     }
-    if (!__ballot(any)) continue;
     // rare: file the passing (row, query) pairs, one at a time, into the queries' lists
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(256, 1) void scan_exact_mfma_kernel(
         }
       }
     }
+    quick = my_cnt < k ? gthr : fmaxf(gthr, thr_s);
   }
   // append this wave's lists (global candidate lists; select_kernel orders them)
   for (uint32_t g = 0; g < EXACT_MFMA_QB; ++g) {
@@ -464,6 +467,7 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_lds_kernel(
 
   float thr_s = NEG_INF;
   uint32_t thr_id = 0xFFFFFFFFu, my_cnt = 0;
+  float quick = gthr;
 
   // prologue: the first NSTAGE - 1 tiles
 #pragma unroll
@@ -520,15 +524,14 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_lds_kernel(
         for (int v = 0; v < 4; ++v) if (row0 + v < row_hi) o[v] = s[v];
       }
     } else {
+      const float smax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));       // (the quick test of scan_exact_mfma_kernel)
+      if (!__ballot(smax >= quick)) continue;
       bool pass[4];
-      bool any = false;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const uint32_t row = row0 + v;
         pass[v] = row < row_hi && s[v] >= gthr && (my_cnt < k || better(s[v], row, thr_s, thr_id));
-        any = any || pass[v];
       }
-      if (!__ballot(any)) continue;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         unsigned long long m = __ballot(pass[v]);
@@ -560,6 +563,7 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_lds_kernel(
           }
         }
       }
+      quick = my_cnt < k ? gthr : fmaxf(gthr, thr_s);
     }
   }
   if constexpr (!SCORES) {
@@ -582,24 +586,27 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_lds_kernel(
 // ================================================================================================
 // fp16 / int8 rows through an fp32 LDS IMAGE (round 4).
 //
-// Every vector instruction between two fp32 MFMAs costs ~10 cycles of the matrix pipe (profiles/r03_mfma_f32_rate.txt), and the
-// kernels above convert an A operand right in front of each MFMA: 86 / 81 TFLOP/s for fp16 / int8 rows where fp32 rows, which
-// need no conversion, reach 101.  Here a tile is converted ONCE per workgroup: each of the four waves fetches a quarter of the
-// raw 16-row tile into registers one tile ahead (coalesced 16-byte loads, 1 KB per wave-instruction; ordinary loads, so the
-// compiler counts them), converts it -- the exact conversions of the reference, vcvtph2ps / vpmovsxbd + vcvtdq2ps
-// (src/simd_dot.cpp:102-124, 160-199) -- and writes it into an fp32 image of the tile in LDS; all four waves then feed their
-// MFMAs from the image with ds_read_b128 and immediate offsets, exactly like fp32 rows.  A quarter of the conversions, none
-// of them inside the MFMA stream.
-//   per tile and wave:  [192 MFMAs on image[t % 2]] -> [epilogue] -> [convert my quarter of tile t+1 into image[(t+1) % 2];
-//                        fetch my quarter of tile t+2] -> s_barrier
+// The kernels above convert an A operand right in front of each MFMA, every wave for itself: four times the conversions, all of
+// them inside the MFMA stream -- 86 / 81 TFLOP/s for fp16 / int8 rows where fp32 rows, which need no conversion, reach 101.
+// Here a tile is converted ONCE per workgroup: each of the four waves brings a quarter of the raw 16-row tile in (direct-to-LDS
+// 16-byte loads, 1 KB per wave-instruction, into a per-lane landing slot), converts it -- the exact conversions of the reference,
+// vcvtph2ps / vpmovsxbd + vcvtdq2ps (src/simd_dot.cpp:102-124, 160-199) -- and writes it into an fp32 image of the tile in LDS;
+// all four waves then feed their MFMAs from the image with ds_read_b128 and immediate offsets, exactly like fp32 rows.
+//   per tile and wave:  192 MFMAs on image[t % 2]; behind them, spread over the K-steps: my quarter of tile t+1 out of its landing
+//                       slots -> image[(t+1) % 2], each slot refilled with tile t+2 as soon as it is empty;  epilogue;  s_barrier
 //   image layout: row r at r * DIM * 4, 16-byte chunk p at position p ^ (r & 15) (the fp32-row build's, conflict-free for the
 //   A-operand reads); the lane -> (row, raw chunk) mapping of the conversion spreads the 16 lanes of a write phase over 2 (fp16) /
 //   4 (int8) rows, so that their fp32 chunks fall into 16 different bank groups without any reordering.
-//   LDS at d = 768: 2 x 48 KB image (+ 32 KB of top-k lists in the scan build).
+//   LDS at d = 768: 2 x 48 KB image + 24 KB (fp16) / 12 KB (int8) of landing slots + 256 B of row scales (+ 32 KB of top-k lists in
+//   the scan build): 152.3 KB of 160.
+// How it got here (profiles/r04_exact_img_ablation.txt; 256 queries x 4M fp16 rows): quarter in registers, converted between two
+// tiles 97 TFLOP/s -> landing slots in LDS 103 -> conversion behind the MFMAs 111 -> one compare in front of the top-k test 113
+// (int8 rows 96 -> 115).  What is left against the MFMA stream alone (133): ~7 % the six direct-to-LDS loads per tile (~40 cycles
+// of the matrix pipe each, more when split into dword loads), ~8 % the conversion, ~5 % epilogue, ~4 % the barrier.
 // Same chains, same order: bit-identical to every other exact kernel (test_exact_scores_on_the_fp32_matrix_cores).
 // ================================================================================================
 template <int DT, int DIM> constexpr bool exact_img_shape() { return DT != DT_F32 && (16 * DIM * exact_bpe<DT>()) % 4096 == 0; }   // whole 1-KB pieces per wave
-template <int DT, int DIM> constexpr int exact_img_bytes() { return 2 * 16 * DIM * 4; }
+template <int DT, int DIM> constexpr int exact_img_bytes() { return 2 * 16 * DIM * 4 + 16 * DIM * exact_bpe<DT>() + 256; }   // two images + the raw tile in flight + row scales
 
 template <int DT, int DIM, bool SCORES>
 __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
   constexpr int RING = 4;                                                          // K-steps of LDS reads in flight
   constexpr int EPC = 16 / BPE;                                                    // elements per raw chunk: 8 halves / 16 bytes
   constexpr int WPC = EPC / 4;                                                     // fp32 chunks per raw chunk: 2 / 4
-  extern __shared__ __attribute__((aligned(16))) char smem[];                      // [image 0 | image 1]
+  extern __shared__ __attribute__((aligned(16))) char smem[];                      // [image 0 | image 1 | raw tile: 4 waves x PPW KB]
   __shared__ float l_s[SCORES ? 1 : 4][SCORES ? 1 : EXACT_MFMA_QB][64];
   __shared__ uint32_t l_id[SCORES ? 1 : 4][SCORES ? 1 : EXACT_MFMA_QB][64];
   const int lane = threadIdx.x & 63;
@@ -625,7 +632,12 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
 
   float bq[T][8];
   exact_load_bq<DIM>(q32, qi, nq, kq, bq);
+#pragma unroll
+  for (int t = 0; t < T; ++t)          // consumed HERE (see exact_mfma_lds_kernel: a wait deferred into the loop would drain the asm loads)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(bq[t][j]));
   const float gthr = (!SCORES && thr != nullptr) ? thr[qi] : NEG_INF;
+  asm volatile("" ::"v"(gthr));
 
   const uint32_t P = gridDim.x, p = blockIdx.x;
   const uint32_t tiles = (row_hi - row_lo + EXACT_MFMA_ROWS - 1) / EXACT_MFMA_ROWS;
@@ -645,48 +657,110 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
   auto pc = [&](int i) -> uint32_t { return WPC == 2 ? 16u * static_cast<uint32_t>(i) + 8u * (lg >> 1) + (l15 >> 1) : 16u * static_cast<uint32_t>(i) + (static_cast<uint32_t>(lane) >> 2); };
   static_assert(CHUNKS_PER_ROW == 16 * PPW, "piece i covers chunks [16 i, 16 i + 16) of the wave's four rows");
   const char* gbase = static_cast<const char*>(rows);
-  // ONE register set, one tile (2.7 us) of prefetch distance.  A second set (the quarter of tile t+2 in flight while t+1 waits to be
-  // converted) was built and measured: 94.8 instead of 99.0 TFLOP/s at 256 queries, 75.4 instead of 78.5 at 64 -- the extra 24
-  // registers cost more than the deeper prefetch gains (profiles/r04_exact_img_bench.txt).
-  uint4 rawreg[1][PPW];
-  float sc_nxt[1][4] = {{1.f, 1.f, 1.f, 1.f}};
-  auto fetch_tile = [&](uint32_t tile, auto SETC) {                // (a tile beyond my range: the last one again, never converted)
-    constexpr int SET = decltype(SETC)::value;
+  // The raw quarter-tile travels HBM -> LDS directly (global_load_lds_dwordx4: lane l's 16 bytes land at piece base + 16 l) and
+  // is read back by the SAME lane when it is converted one iteration later: LDS as the landing zone of an asynchronous load, no
+  // register is held across the MFMA stream and only this wave's own vmcnt orders it (no barrier).  With the quarter in registers
+  // instead (24 VGPRs live across the loop of a kernel that already uses all 256) hipcc split a live range right behind the loads
+  // -- `s_waitcnt vmcnt(0); v_mov` after the fifth of six -- and every tile paid a full memory latency: 18 % of the kernel
+  // (profiles/r04_exact_img_ablation.txt).  The loads are issued from inline asm and counted by hand, as in the kernel above; the
+  // int8 row scales take the same road (an ordinary load's compiler-made wait would drain the prefetch).
+  //   LPT loads per wave and tile, in this order: pieces 0 .. PPW-1, then (int8) the 16 row scales.  Slot i is refilled -- with the
+  //   tile after next -- right after it has been read, so whenever slot i is about to be read exactly LPT - 1 younger loads may
+  //   still be in flight: s_waitcnt vmcnt(LPT - 1).  (A store of the score build in between only makes that wait stricter.)
+  constexpr int LPT = PPW + (DT == DT_I8 ? 1 : 0);
+  const uint32_t lds_raw = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem))) + 2u * IMG_BYTES + wave * (PPW * 1024u);
+  const uint32_t lds_sc = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NVDB_LPTR(smem))) + 2u * IMG_BYTES + 4u * (PPW * 1024u) + wave * 64u;
+  const char* my_raw = smem + 2 * IMG_BYTES + wave * (PPW * 1024) + lane * 16;
+  const char* my_sc = smem + 2 * IMG_BYTES + 4 * (PPW * 1024) + wave * 64 + kq * 16;       // scales of rows 4 kq .. + 3
+  auto fetch_piece = [&](uint32_t tile, int i) {                   // (a tile beyond my range: the last one again, never converted)
     const uint32_t tl = tile < t_hi ? tile : t_hi - 1;
+    uint32_t r = row_lo + tl * EXACT_MFMA_ROWS + pr(i);
+    r = r < row_hi ? r : row_hi - 1;
+    glds16_v(gbase + static_cast<uint64_t>(r) * ROW_BYTES + (pc(i) << 4), lds_raw + static_cast<uint32_t>(i) * 1024u);
+  };
+  auto fetch_scales = [&](uint32_t tile) {
+    if constexpr (DT == DT_I8) {
+      const uint32_t tl = tile < t_hi ? tile : t_hi - 1;
+      uint32_t r = row_lo + tl * EXACT_MFMA_ROWS + static_cast<uint32_t>(x15);
+      r = r < row_hi ? r : row_hi - 1;
+      if (lane < 16) glds4_v(scales + r, lds_sc);
+    }
+  };
+  // slot i, read into registers one K-step earlier (landed: the reader has waited) -> fp32 -> image of `tile`
+  auto convert_piece = [&](uint32_t tile, int i, const uint4& raw) {
+    char* img = smem + (tile & 1u) * IMG_BYTES;
+    const uint32_t r = pr(i), c = pc(i);
+    float x[EPC];
+    if constexpr (DT == DT_F16) {
+      ExactRaw<DT_F16> rw; rw.v = raw;
+      exact_raw_to_f32<DT_F16>(rw, x);
+    } else {
+      ExactRaw<DT_I8> lo, hi; lo.v = make_uint2(raw.x, raw.y); hi.v = make_uint2(raw.z, raw.w);
+      float xl[8], xh[8];
+      exact_raw_to_f32<DT_I8>(lo, xl); exact_raw_to_f32<DT_I8>(hi, xh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[e] = xl[e]; x[8 + e] = xh[e]; }
+    }
+#pragma unroll
+    for (int j = 0; j < WPC; ++j) {
+      const uint32_t pos = (WPC * c + static_cast<uint32_t>(j)) ^ (r & 15u);
+      *reinterpret_cast<float4*>(img + r * IMG_ROW + (pos << 4)) = make_float4(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
+    }
+  };
+  auto read_piece = [&](int i) -> uint4 { return *reinterpret_cast<const uint4*>(my_raw + i * 1024); };
+  float sc_nxt[4] = {1.f, 1.f, 1.f, 1.f};
+  auto read_scales = [&]() {
+    if constexpr (DT == DT_I8) {
+      const float4 v = *reinterpret_cast<const float4*>(my_sc);
+      sc_nxt[0] = v.x; sc_nxt[1] = v.y; sc_nxt[2] = v.z; sc_nxt[3] = v.w;
+    }
+  };
+  // Inside the tile loop (K-step t and MFMA j are compile-time constants after unrolling): piece i of tile + 1 is read out of its slot
+  // behind the MFMAs of K-step conv_step(i) - 1, and converted one element (fp16) / two (int8) behind EACH of the eight MFMAs of
+  // K-step conv_step(i): a vector instruction issued while an MFMA runs costs ~3 cycles of the matrix pipe
+  // (profiles/r03_mfma_f32_rate.txt), a serial conversion phase between two tiles cost ~1600 cycles per tile
+  // (profiles/r04_exact_img_ablation.txt).  The slot is refilled with tile + 2 as soon as its bytes are in registers.  All of it is
+  // unconditional: behind my last tile the (clamped) prefetch is converted into the image nobody reads any more.
+  auto conv_step = [](int i) constexpr { return ((2 * i + 1) * T) / (2 * PPW); };
+  static_assert(T / PPW >= 4, "a piece's read and conversion steps do not collide with its neighbours'");
+  // image write addresses: fp32 chunk jj of raw chunk 16 i + cl of row r lands at 16-byte position WPC * 16 * i + ((WPC * cl + jj) ^ (r & 15))
+  // (the XOR stays inside the low four bits): one base per jj, the piece is an immediate
+  uint32_t wbase[WPC];
+#pragma unroll
+  for (int jj = 0; jj < WPC; ++jj) wbase[jj] = pr(0) * IMG_ROW + (((WPC * pc(0) + static_cast<uint32_t>(jj)) ^ (pr(0) & 15u)) << 4);
+  uint4 rawv = make_uint4(0u, 0u, 0u, 0u);
+  float cx[EPC];
+  auto raw_dword = [&](int d) -> uint32_t { return d == 0 ? rawv.x : d == 1 ? rawv.y : d == 2 ? rawv.z : rawv.w; };
+  auto micro_convert = [&](uint32_t tile, int i, int j) {         // behind MFMA j of K-step conv_step(i) of `tile`: piece i of tile + 1
+    char* wimg = smem + ((tile + 1u) & 1u) * IMG_BYTES + i * (WPC * 256);
+    const uint32_t d = raw_dword(j >> 1);
+    if constexpr (DT == DT_F16) {
+      cx[j] = half_bits_to_float((j & 1) ? d >> 16 : d & 0xFFFFu);
+      if ((j & 3) == 3) *reinterpret_cast<float4*>(wimg + wbase[j >> 2]) = make_float4(cx[j - 3], cx[j - 2], cx[j - 1], cx[j]);
+    } else {
+      const int b = 2 * (j & 1);
+      cx[2 * j] = static_cast<float>(static_cast<int>(d << (24 - 8 * b)) >> 24);
+      cx[2 * j + 1] = static_cast<float>(static_cast<int>(d << (16 - 8 * b)) >> 24);
+      if (j & 1) *reinterpret_cast<float4*>(wimg + wbase[j >> 1]) = make_float4(cx[2 * j - 2], cx[2 * j - 1], cx[2 * j], cx[2 * j + 1]);
+    }
+    if (j == 7) fetch_piece(tile + 2, i);                           // (the slot's old bytes are in registers)
+  };
+  auto staged_reads = [&](uint32_t tile, int t) {                  // behind the MFMAs of K-step t
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      uint32_t r = row_lo + tl * EXACT_MFMA_ROWS + pr(i);
-      r = r < row_hi ? r : row_hi - 1;
-      rawreg[SET][i] = *reinterpret_cast<const uint4*>(gbase + static_cast<uint64_t>(r) * ROW_BYTES + (pc(i) << 4));
+      if (t == conv_step(i) - 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT - 1) : "memory");
+        rawv = read_piece(i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if constexpr (DT == DT_I8) {
-      const uint32_t r0 = row_lo + tl * EXACT_MFMA_ROWS + 4u * static_cast<uint32_t>(kq);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) sc_nxt[SET][v] = scales[r0 + v < row_hi ? r0 + v : row_hi - 1];
-    }
-    __builtin_amdgcn_sched_barrier(0);                             // issued HERE, a whole tile ahead of their use
-  };
-  auto convert_tile = [&](uint32_t tile, auto SETC) {
-    constexpr int SET = decltype(SETC)::value;
-    char* img = smem + (tile & 1u) * IMG_BYTES;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const uint32_t r = pr(i), c = pc(i);
-      float x[EPC];
-      if constexpr (DT == DT_F16) {
-        ExactRaw<DT_F16> rw; rw.v = rawreg[SET][i];
-        exact_raw_to_f32<DT_F16>(rw, x);
-      } else {
-        ExactRaw<DT_I8> lo, hi; lo.v = make_uint2(rawreg[SET][i].x, rawreg[SET][i].y); hi.v = make_uint2(rawreg[SET][i].z, rawreg[SET][i].w);
-        float xl[8], xh[8];
-        exact_raw_to_f32<DT_I8>(lo, xl); exact_raw_to_f32<DT_I8>(hi, xh);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { x[e] = xl[e]; x[8 + e] = xh[e]; }
-      }
-#pragma unroll
-      for (int j = 0; j < WPC; ++j) {
-        const uint32_t pos = (WPC * c + static_cast<uint32_t>(j)) ^ (r & 15u);
-        *reinterpret_cast<float4*>(img + r * IMG_ROW + (pos << 4)) = make_float4(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
+      if (t == T - 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT - 1) : "memory");
+        read_scales();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (read before the slot is refilled)
+        fetch_scales(tile + 2);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -705,22 +779,29 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
 
   float thr_s = NEG_INF;
   uint32_t thr_id = 0xFFFFFFFFu, my_cnt = 0;
+  float quick = gthr;
   float sc_cur[4] = {1.f, 1.f, 1.f, 1.f};
 
   // prologue: image of the first tile; my quarter of the second on its way
-  using S0 = std::integral_constant<int, 0>;
-  fetch_tile(t_lo, S0{});
-  convert_tile(t_lo, S0{});
 #pragma unroll
-  for (int v = 0; v < 4; ++v) sc_cur[v] = sc_nxt[0][v];
-  fetch_tile(t_lo + 1, S0{});
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // my image writes have been performed before I signal
+  for (int i = 0; i < PPW; ++i) fetch_piece(t_lo, i);
+  fetch_scales(t_lo);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) convert_piece(t_lo, i, read_piece(i));
+  read_scales();
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sc_cur[v] = sc_nxt[v];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // slots read, my image writes performed before I signal
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) fetch_piece(t_lo + 1, i);
+  fetch_scales(t_lo + 1);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  // one tile: MFMAs out of image tile & 1, epilogue, then my quarter of tile + 1 (in registers since the previous iteration) ->
-  // the other image, and tile + 2 is fetched into the registers just freed
-  auto one_tile = [&](uint32_t tile, auto NEXTSET) {
+  // one tile: MFMAs out of image tile & 1 with my quarter of tile + 1 converted into the other image (and tile + 2 fetched) behind
+  // them, epilogue, barrier
+  auto one_tile = [&](uint32_t tile) {
     const char* img = smem + (tile & 1u) * IMG_BYTES;
     ExactRaw<DT_F32> ring[RING];
 #pragma unroll
@@ -735,8 +816,16 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
       for (int j = 0; j < 8; ++j) {
         if (t == 0) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], bq[0][j], floatx4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         else acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], bq[t][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+          if (t == conv_step(i)) {
+            micro_convert(tile, i, j);
+            __builtin_amdgcn_sched_barrier(0);                     // pinned behind MFMA j
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
+      staged_reads(tile, t);
     }
     float s[4];
 #pragma unroll
@@ -757,15 +846,16 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
         for (int v = 0; v < 4; ++v) if (row0 + v < row_hi) o[v] = s[v];
       }
     } else {
-      bool pass[4];
-      bool any = false;
+      // one compare per tile and lane in front of the full test: a row can only enter with a score >= quick (= the bar handed in
+      // and, once my list is full, its k-th score; NaN scores never enter, as before)
+      const float smax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+      if (__ballot(smax >= quick)) {
+        bool pass[4];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const uint32_t row = row0 + v;
-        pass[v] = row < row_hi && s[v] >= gthr && (my_cnt < k || better(s[v], row, thr_s, thr_id));
-        any = any || pass[v];
-      }
-      if (__ballot(any)) {
+        for (int v = 0; v < 4; ++v) {
+          const uint32_t row = row0 + v;
+          pass[v] = row < row_hi && s[v] >= gthr && (my_cnt < k || better(s[v], row, thr_s, thr_id));
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           unsigned long long m = __ballot(pass[v]);
@@ -797,19 +887,19 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
             }
           }
         }
+        quick = my_cnt < k ? gthr : fmaxf(gthr, thr_s);
       }
     }
-    if (tile + 1 < t_hi) {
-      convert_tile(tile + 1, NEXTSET);
+    if constexpr (DT == DT_I8) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) sc_cur[v] = sc_nxt[decltype(NEXTSET)::value][v];
-      fetch_tile(tile + 2, NEXTSET);
+      for (int v = 0; v < 4; ++v) sc_cur[v] = sc_nxt[v];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // image (tile + 1) & 1 complete; everybody is done reading image tile & 1
     asm volatile("" ::: "memory");
   };
-  for (uint32_t tile = t_lo; tile < t_hi; ++tile) one_tile(tile, S0{});
+  for (uint32_t tile = t_lo; tile < t_hi; ++tile) one_tile(tile);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the prefetch that ran past my range)
   if constexpr (!SCORES) {
     for (uint32_t g = 0; g < EXACT_MFMA_QB; ++g) {
       const uint32_t q = qg0 + wave * EXACT_MFMA_QB + g;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One configuration of the exact path for a rocprofv3 pass:  exact_one.py <f16|i8|f32> <nq> <rows> <mode: lds|reg|valu> [reps]"""
+"""One configuration of the exact path for a rocprofv3 pass:  exact_one.py <f16|i8|f32> <nq> <rows> <mode: img|lds|reg|valu> [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nano-vectordb_amd"))
@@ -10,7 +10,8 @@ ctx = nvdb_amd.HipContext(0)
 ctx.generate_corpus(20240613, n, 768, {"f16": nvdb_amd.DT_F16, "i8": nvdb_amd.DT_I8, "f32": nvdb_amd.DT_F32}[tag])
 ctx.set_option("path", 1)
 ctx.set_option("exact_mfma", 0 if mode == "valu" else 1)
-ctx.set_option("exact_lds", 2 if mode == "lds" else 0)
+ctx.set_option("exact_img", 1 if mode == "img" else 0)
+ctx.set_option("exact_lds", 2 if mode == "lds" else 1 if mode == "img" else 0)
 q = nvdb_amd.synth_rows_f32(20240614, 0, nq, 768)
 for _ in range(reps):
     ids, sc, t = ctx.search_batch(q, 10, want_timing=True)
