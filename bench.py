@@ -724,9 +724,12 @@ def main():
                 el_ = timed_passes(ctx, 64, reps=2)
                 ex["fp32_mfma" if mf else "valu"] = {"ms_per_pass": el_ * 1e3, "TFLOPs": 2.0 * 64 * N * D / el_ / 1e12}
             ctx.set_option("exact_mfma", 1)
+            el_ = timed_passes(ctx, 256, reps=2)
+            ex["fp32_mfma_256_queries"] = {"ms_per_pass": el_ * 1e3, "TFLOPs": 2.0 * 256 * N * D / el_ / 1e12}
             ctx.set_option("path", args.path)
-            extras["exact_path_batch64"] = {"workload": f"exact fp32-order scan (path 1), fp16 corpus N={N} d={D}, 64 queries", **ex,
-                                            "kernels": "scan_exact_mfma_kernel (v_mfma_f32_16x16x4_f32, eight accumulator tiles = the reference's eight fma chains) vs scan_exact_kernel (VALU)",
+            extras["exact_path_batch64"] = {"workload": f"exact fp32-order scan (path 1), fp16 corpus N={N} d={D}, 64 queries (fp32_mfma_256_queries: 256)", **ex,
+                                            "kernels": "exact_mfma_img_kernel (v_mfma_f32_16x16x4_f32, eight accumulator tiles = the reference's eight fma chains; rows converted "
+                                                       "once per workgroup into an fp32 LDS image) vs scan_exact_kernel (VALU)",
                                             "fp32_matrix_peak_TFLOPs": 157.3}
             # (2) BASELINE configs[2]: int8(+scale), same shape
             c8 = nvdb_amd.HipContext(local_rank)
