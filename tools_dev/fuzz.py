@@ -56,6 +56,7 @@ for ci in range(cases):
         ok = False; st = {"error": str(e)}
     for k_ in opts: ctx.set_option(k_, {"tile_permute": 1, "chunk_growth": 0, "mfma_boot": 1, "sibling_sync": 1, "xcd_balance": 1, "i8_defer": 0, "i8_lo_bits": 7, "boot_tiles": 0, "exact_mfma": 1, "exact_lds": 1, "exact_img": 1, "exact_wgs": 1, "fuse": 1, "zero_copy": 1}[k_])
     ctx.set_option("path", 0)
+    if (ci + 1) % 50 == 0: print(f"  .. {ci + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)      # (a long run keeps talking)
     if not ok:
         fails += 1
         print(f"FAIL case {ci}: {tag} n={n} dim={dim} nq={nq} k={k} q8_shadow={q8} opts={opts} stats={st}", flush=True)
