@@ -615,6 +615,7 @@ __global__ __launch_bounds__(256, 1) void exact_mfma_img_kernel(
     Cand* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t* __restrict__ overflow,
     float* __restrict__ out, uint64_t ld) {
   static_assert(DT != DT_F32 && DIM % 32 == 0 && DIM <= 768 && exact_img_shape<DT, DIM>(), "fp16 / int8 rows; whole 1-KB pieces per wave");
+  static_assert(exact_img_bytes<DT, DIM>() + (SCORES ? 1 : 4 * EXACT_MFMA_QB) * 64 * 8 <= 160 * 1024, "images + landing slots + top-k lists fit the 160 KB of LDS");
   constexpr int BPE = exact_bpe<DT>(), T = DIM / 32, ROW_BYTES = DIM * BPE, CHUNKS_PER_ROW = ROW_BYTES / 16;
   constexpr int IMG_ROW = DIM * 4, IMG_BYTES = 16 * IMG_ROW;
   constexpr int PIECES = 16 * ROW_BYTES / 1024, PPW = PIECES / 4;                   // 16-byte raw chunks per lane and tile
