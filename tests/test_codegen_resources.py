@@ -133,3 +133,25 @@ def test_rendezvous_registers_and_hand_placed_instructions(codegen):
     k = _find(by_name, "refine_l2_rows_kernel<768>")
     body = _body(asm, k["mangled"])
     assert body.count("v_fma_mix_f32") == 192 and body.count("v_cvt_f32_f16") == 0 and body.count("global_load_lds_dwordx4") == 24
+
+
+def test_exact_image_kernel_keeps_its_prefetch_out_of_the_compilers_hands(codegen):
+    """exact_mfma_img_kernel (csrc/kernels_exact_mfma.h): the raw tile lands in LDS slots through direct-to-LDS loads counted by hand.
+    The build that kept it in registers lost 18 % to ONE compiler-made `s_waitcnt vmcnt(0)` behind the loads of every tile
+    (profiles/r04_exact_img_ablation.txt); this pins what the tile loop may contain."""
+    by_name, asm = codegen
+    for name, pieces in (("exact_mfma_img_kernel<2, 768, false>", 6), ("exact_mfma_img_kernel<3, 768, false>", 3)):
+        k = _find(by_name, name)
+        assert k["vgpr"] + k["agpr"] <= 512 and k["occ"] == 1, (name, k)
+        start = asm.index(f"\n{k['mangled']}:")
+        body = asm[start:asm.index(".Lfunc_end", start)]                                     # (_body stops at the early-exit s_endpgm)
+        tag = "BB" + re.search(r"\.LBB(\d+_\d+):\s*; =>This Loop Header: Depth=1", body).group(1)
+        # the tile loop = every basic block whose label comment names that header (the loop is laid out rotated: its tail precedes it)
+        loop = "\n".join(b for b in re.split(r"\n(?=\.LBB\d+_\d+:)", body) if tag in "\n".join(b.split("\n")[:6]))
+        assert loop.count("v_mfma_f32_16x16x4_f32") == 192, (name, loop.count("v_mfma_f32_16x16x4_f32"))
+        lpt = pieces + (1 if name.startswith("exact_mfma_img_kernel<3") else 0)               # int8: + the row scales
+        assert loop.count("global_load_lds_dwordx4") == pieces and loop.count("s_barrier") == 1, name
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)
+        assert waits and all(int(w) == lpt - 1 for w in waits), (name, waits)                 # the hand-counted ones, nothing else
+        assert "global_load_dwordx4" not in loop.replace("global_load_lds_dwordx4", ""), name  # no register-bound row loads in the loop
+
